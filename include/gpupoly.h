@@ -1,0 +1,167 @@
+/*
+ * gpupoly.h — C ABI of libgpupoly for AMD MI355X (gfx950).
+ *
+ * Drop-in boundary for the `gpu` feature of MachinaIO/mxx: every entry point
+ * below replaces the function of the same name that mxx's Rust side binds in
+ *   src/poly/dcrt/gpu.rs:69-240  (unsafe extern "C" block)
+ * and that its CUDA tree declares in
+ *   cuda/include/Runtime.cuh:20-44,108
+ *   cuda/include/matrix/MatrixData.cuh:10-27
+ *   cuda/include/matrix/MatrixArith.cuh:10-26
+ *   cuda/include/matrix/MatrixNTT.cuh:9-10
+ *   cuda/include/matrix/MatrixDecompose.cuh:26-37
+ *   cuda/include/matrix/MatrixSampling.cuh:25-37
+ *   cuda/include/matrix/MatrixTrapdoor.cuh:66-101
+ *   cuda/include/matrix/MatrixSerde.cuh:10-58
+ * (paths relative to the reference checkout).
+ *
+ * Conventions:
+ *   - int-returning functions: 0 = ok, non-zero = error; the message is
+ *     available from gpu_last_error() (thread-local, valid until the next
+ *     error on that thread).  Nothing throws across this boundary.
+ *   - *_create hands out an owning pointer; *_destroy is stream-ordered and
+ *     may be called while device work on the object is still in flight.
+ *   - handles may be used concurrently from several host threads.
+ *   - compute entry points do not block the host; load/store *_batch return
+ *     an event set (possibly NULL) the caller waits on and destroys;
+ *     gpu_matrix_equal and the compact-bytes pair are synchronous.
+ *   - device layout is private: words [poly][limb][N], poly = row*cols + col,
+ *     uint32_t residues when every modulus is < 2^32, uint64_t otherwise.
+ *   - EVAL format is OpenFHE's: slot k of limb i holds a(psi_i^(2*bitrev(k)+1))
+ *     with psi_i the minimum primitive 2N-th root mod q_i (the reference CPU
+ *     path's convention), so EVAL bytes are interchangeable with the CPU side.
+ */
+#ifndef GPUPOLY_H
+#define GPUPOLY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct GpuContext GpuContext;
+typedef struct GpuMatrix GpuMatrix;
+typedef struct GpuEventSet GpuEventSet;
+typedef struct GpuP1CovarianceCache GpuP1CovarianceCache;
+
+/* src/poly/dcrt/gpu.rs:45-61, cuda/include/ChaCha.cuh:9-12 — passed BY VALUE */
+typedef struct GpuRngSeed {
+    uint64_t words[4];
+} GpuRngSeed;
+
+/* src/poly/dcrt/gpu.rs:242-247 */
+#define GPU_POLY_FORMAT_COEFF 0
+#define GPU_POLY_FORMAT_EVAL 1
+#define GPU_MATRIX_DIST_UNIFORM 0
+#define GPU_MATRIX_DIST_GAUSS 1
+#define GPU_MATRIX_DIST_BIT 2
+#define GPU_MATRIX_DIST_TERNARY 3
+
+/* ---- runtime: cuda/include/Runtime.cuh:20-44,108 ------------------------- */
+/* L = moduli_len - 1 (top level); gpu_ids[0] is the device the context lives on. */
+int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, const uint64_t *moduli, size_t moduli_len,
+                       const int *gpu_ids, size_t gpu_ids_len, GpuContext **out_ctx);
+void gpu_context_destroy(GpuContext *ctx);
+int gpu_context_get_N(const GpuContext *ctx, int *out_N);
+
+int gpu_event_set_wait(GpuEventSet *events);
+void gpu_event_set_destroy(GpuEventSet *events);
+
+int gpu_device_count(int *out_count);
+int gpu_device_mem_info(int device, size_t *out_free, size_t *out_total);
+int gpu_device_synchronize(void);
+int gpu_device_reset(void);
+
+const char *gpu_last_error(void);
+int gpu_set_last_error(const char *msg);
+
+void *gpu_pinned_alloc(size_t bytes);
+void gpu_pinned_free(void *ptr);
+
+/* ---- storage: cuda/include/matrix/MatrixData.cuh:10-27 -------------------- */
+/* contents undefined after create; a matrix at `level` uses limbs 0..=level */
+int gpu_matrix_create(GpuContext *ctx, int level, size_t rows, size_t cols, int format, GpuMatrix **out);
+void gpu_matrix_destroy(GpuMatrix *mat);
+int gpu_matrix_copy(GpuMatrix *dst, const GpuMatrix *src);
+int gpu_matrix_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,
+                          size_t src_col, size_t rows, size_t cols);
+
+/* ---- arithmetic: cuda/include/matrix/MatrixArith.cuh:10-26 ---------------- */
+int gpu_matrix_add(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
+int gpu_matrix_sub(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
+int gpu_matrix_add_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,
+                         size_t src_col, size_t rows, size_t cols);
+int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);          /* both EVAL */
+int gpu_matrix_mul_scalar(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *scalar); /* scalar is 1x1, EVAL */
+int gpu_matrix_equal(const GpuMatrix *lhs, const GpuMatrix *rhs, int *out_equal);
+
+/* ---- NTT: cuda/include/matrix/MatrixNTT.cuh:9-10 (idempotent) -------------- */
+int gpu_matrix_ntt_all(GpuMatrix *mat);
+int gpu_matrix_intt_all(GpuMatrix *mat);
+
+/* ---- gadget / decompose: cuda/include/matrix/MatrixDecompose.cuh:26-37 ---- */
+int gpu_matrix_fill_gadget(GpuMatrix *out, uint32_t base_bits);
+int gpu_matrix_fill_small_gadget(GpuMatrix *out, uint32_t base_bits);
+int gpu_matrix_fill_small_decomposed_identity_chunk(GpuMatrix *out, const GpuMatrix *scalar_by_digit,
+                                                    size_t chunk_idx);
+int gpu_matrix_decompose_base(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *out);
+int gpu_matrix_decompose_base_small(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *out);
+
+/* ---- sampling: MatrixSampling.cuh:25-37, MatrixTrapdoor.cuh:66-101 --------- */
+int gpu_matrix_sample_distribution(GpuMatrix *out, int dist_type, double sigma, GpuRngSeed seed);
+int gpu_matrix_sample_distribution_columns(GpuMatrix *out, int dist_type, double sigma, GpuRngSeed seed,
+                                           size_t full_ncol, size_t col_offset);
+int gpu_matrix_gauss_samp_gq_arb_base(GpuMatrix *src, uint32_t base_bits, double c, double dgg_stddev,
+                                      GpuRngSeed seed, GpuMatrix *out);
+int gpu_matrix_sample_p1_full(const GpuMatrix *a_mat, const GpuMatrix *b_mat, const GpuMatrix *d_mat,
+                              const GpuMatrix *tp2, double sigma, double s, double dgg_stddev, GpuRngSeed seed,
+                              GpuMatrix *out);
+int gpu_matrix_create_p1_covariance_cache(const GpuMatrix *a_mat, const GpuMatrix *b_mat, const GpuMatrix *d_mat,
+                                          double sigma, double s, double dgg_stddev,
+                                          GpuP1CovarianceCache **out_cache);
+void gpu_matrix_destroy_p1_covariance_cache(GpuP1CovarianceCache *cache);
+int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cache, const GpuMatrix *tp2, GpuRngSeed seed,
+                                     GpuMatrix *out);
+
+/* ---- serde: cuda/include/matrix/MatrixSerde.cuh:10-58 ---------------------- */
+/* host layout [poly][limb][N] little-endian u64, poly stride = bytes_per_poly */
+int gpu_matrix_load_rns_batch(GpuMatrix *mat, const uint8_t *bytes, size_t bytes_per_poly, int format,
+                              GpuEventSet **out_events);
+int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_out, size_t bytes_per_poly, int format,
+                               GpuEventSet **out_events);
+int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t *words_out, size_t words_per_poly,
+                                       GpuEventSet **out_events);
+int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_out, size_t payload_capacity,
+                                   uint16_t *out_max_coeff_bits, uint16_t *out_bytes_per_coeff,
+                                   size_t *out_payload_len);
+int gpu_matrix_load_compact_bytes(GpuMatrix *mat, const uint8_t *payload, size_t payload_len,
+                                  uint16_t max_coeff_bits);
+int gpu_poly_store_compact_bytes(GpuMatrix *poly, uint8_t *payload_out, size_t payload_capacity,
+                                 uint16_t *out_max_coeff_bits, uint16_t *out_bytes_per_coeff,
+                                 size_t *out_payload_len);
+int gpu_poly_load_compact_bytes(GpuMatrix *poly, const uint8_t *payload, size_t payload_len,
+                                uint16_t max_coeff_bits);
+
+/* ---- MI355X extensions (not in the reference ABI; prefixed gpupoly_) ------- */
+/* Fused S * G^-1(B): never materialises the k-times larger digit matrix
+ * (replaces the Rust-side loop src/matrix/gpu_dcrt_poly.rs:1414-1493).       */
+int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);
+/* hipEvent timing on the context's compute stream (bench.py's roofline leg). */
+int gpupoly_timer_start(GpuContext *ctx);
+int gpupoly_timer_stop(GpuContext *ctx, float *out_ms);
+/* Non-blocking event marks on the compute stream (slot < 65536) and the elapsed
+ * time between two marks once both have completed (blocks on the later one).    */
+int gpupoly_timer_mark(GpuContext *ctx, uint32_t slot);
+int gpupoly_timer_elapsed(GpuContext *ctx, uint32_t slot_begin, uint32_t slot_end, float *out_ms);
+/* raw device pointer / byte size of a matrix (zero-copy interop, e.g. RCCL).  */
+int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, size_t *out_bytes);
+int gpupoly_context_device(const GpuContext *ctx, int *out_device);
+int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes);
+const char *gpupoly_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUPOLY_H */

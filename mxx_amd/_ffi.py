@@ -1,0 +1,157 @@
+"""ctypes binding of libgpupoly.so (include/gpupoly.h).
+
+This is the same binding surface the reference's Rust side declares in
+`src/poly/dcrt/gpu.rs:69-240`.  The library is mandatory: importing any
+compute-facing part of `mxx_amd` without the built HIP library raises — there is
+no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpupoly.so")
+
+GPU_POLY_FORMAT_COEFF = 0
+GPU_POLY_FORMAT_EVAL = 1
+GPU_MATRIX_DIST_UNIFORM = 0
+GPU_MATRIX_DIST_GAUSS = 1
+GPU_MATRIX_DIST_BIT = 2
+GPU_MATRIX_DIST_TERNARY = 3
+
+
+class GpuPolyError(RuntimeError):
+    """Raised where the reference's Rust wrapper panics (`check_status`, gpu.rs:259-263)."""
+
+
+class GpuRngSeed(C.Structure):
+    """`struct { uint64_t words[4]; }` passed by value (gpu.rs:45-61)."""
+
+    _fields_ = [("words", C.c_uint64 * 4)]
+
+    @classmethod
+    def from_bytes(cls, b: bytes) -> "GpuRngSeed":
+        if len(b) != 32:
+            raise ValueError("seed must be 32 bytes")
+        s = cls()
+        for i in range(4):
+            s.words[i] = int.from_bytes(b[8 * i : 8 * i + 8], "little")
+        return s
+
+    def to_bytes(self) -> bytes:
+        return b"".join(int(w).to_bytes(8, "little") for w in self.words)
+
+
+_vp = C.c_void_p
+_sz = C.c_size_t
+_u8p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); every symbol include/gpupoly.h declares
+SIGNATURES = {
+    "gpu_context_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _sz, C.POINTER(C.c_int), _sz, C.POINTER(_vp)]),
+    "gpu_context_destroy": (None, [_vp]),
+    "gpu_context_get_N": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gpu_event_set_wait": (C.c_int, [_vp]),
+    "gpu_event_set_destroy": (None, [_vp]),
+    "gpu_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gpu_device_mem_info": (C.c_int, [C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    "gpu_device_synchronize": (C.c_int, []),
+    "gpu_device_reset": (C.c_int, []),
+    "gpu_last_error": (C.c_char_p, []),
+    "gpu_set_last_error": (C.c_int, [C.c_char_p]),
+    "gpu_pinned_alloc": (_vp, [_sz]),
+    "gpu_pinned_free": (None, [_vp]),
+    "gpu_matrix_create": (C.c_int, [_vp, C.c_int, _sz, _sz, C.c_int, C.POINTER(_vp)]),
+    "gpu_matrix_destroy": (None, [_vp]),
+    "gpu_matrix_copy": (C.c_int, [_vp, _vp]),
+    "gpu_matrix_copy_block": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz]),
+    "gpu_matrix_add": (C.c_int, [_vp, _vp, _vp]),
+    "gpu_matrix_sub": (C.c_int, [_vp, _vp, _vp]),
+    "gpu_matrix_add_block": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz]),
+    "gpu_matrix_mul": (C.c_int, [_vp, _vp, _vp]),
+    "gpu_matrix_mul_scalar": (C.c_int, [_vp, _vp, _vp]),
+    "gpu_matrix_equal": (C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
+    "gpu_matrix_ntt_all": (C.c_int, [_vp]),
+    "gpu_matrix_intt_all": (C.c_int, [_vp]),
+    "gpu_matrix_fill_gadget": (C.c_int, [_vp, C.c_uint32]),
+    "gpu_matrix_fill_small_gadget": (C.c_int, [_vp, C.c_uint32]),
+    "gpu_matrix_fill_small_decomposed_identity_chunk": (C.c_int, [_vp, _vp, _sz]),
+    "gpu_matrix_decompose_base": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "gpu_matrix_decompose_base_small": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "gpu_matrix_sample_distribution": (C.c_int, [_vp, C.c_int, C.c_double, GpuRngSeed]),
+    "gpu_matrix_sample_distribution_columns": (C.c_int, [_vp, C.c_int, C.c_double, GpuRngSeed, _sz, _sz]),
+    "gpu_matrix_gauss_samp_gq_arb_base": (C.c_int, [_vp, C.c_uint32, C.c_double, C.c_double, GpuRngSeed, _vp]),
+    "gpu_matrix_sample_p1_full": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, GpuRngSeed, _vp]),
+    "gpu_matrix_create_p1_covariance_cache": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.POINTER(_vp)]),
+    "gpu_matrix_destroy_p1_covariance_cache": (None, [_vp]),
+    "gpu_matrix_sample_p1_full_cached": (C.c_int, [_vp, _vp, GpuRngSeed, _vp]),
+    "gpu_matrix_load_rns_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, C.POINTER(_vp)]),
+    "gpu_matrix_store_rns_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, C.POINTER(_vp)]),
+    "gpu_matrix_store_const_coeff_batch": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "gpu_matrix_store_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(_sz)]),
+    "gpu_matrix_load_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.c_uint16]),
+    "gpu_poly_store_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(_sz)]),
+    "gpu_poly_load_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.c_uint16]),
+    "gpupoly_matrix_mul_decompose": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "gpupoly_timer_start": (C.c_int, [_vp]),
+    "gpupoly_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "gpupoly_timer_mark": (C.c_int, [_vp, C.c_uint32]),
+    "gpupoly_timer_elapsed": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "gpupoly_matrix_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "gpupoly_context_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gpupoly_context_word_bytes": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gpupoly_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgpupoly.so; fail loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpuPolyError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C mxx_amd/csrc`). mxx_amd has no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error_string() -> str:
+    msg = lib().gpu_last_error()
+    return msg.decode("utf-8", "replace") if msg else "unknown GPU error"
+
+
+def check_status(code: int, context: str) -> None:
+    if code != 0:
+        raise GpuPolyError(f"{context} failed: {last_error_string()}")
+
+
+def gpu_device_sync() -> None:
+    check_status(lib().gpu_device_synchronize(), "gpu_device_synchronize")
+
+
+def detected_gpu_device_ids() -> list[int]:
+    n = C.c_int(0)
+    if lib().gpu_device_count(C.byref(n)) != 0 or n.value <= 0:
+        return []
+    return list(range(n.value))
+
+
+def detected_gpu_device_count() -> int:
+    return len(detected_gpu_device_ids())
+
+
+def wait_and_destroy_events(events: _vp) -> None:
+    if events:
+        st = lib().gpu_event_set_wait(events)
+        lib().gpu_event_set_destroy(events)
+        check_status(st, "gpu_event_set_wait")

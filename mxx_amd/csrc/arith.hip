@@ -1,0 +1,349 @@
+// arith.hip — coefficient-wise modular add/sub/mul and matrix x matrix over R_q.
+// Replaces cuda/src/matrix/MatrixArith.cu behind cuda/include/matrix/MatrixArith.cuh:10-26.
+//
+// Matrix product (EVAL domain): for every limb and every evaluation slot i,
+//   C[r,c](i) = sum_k A[r,k](i) * B[k,c](i)  mod q_limb
+// (reference semantics: src/matrix/base/memory.rs:450-480,589-605 on the CPU side,
+//  cuda/src/matrix/MatrixArith.cu:191-287 on the CUDA side).  Slots are the fastest
+// axis in HBM, so lanes map to consecutive slots (16 B per lane when SV = 4) and
+// each thread keeps a TR x TC register tile of 64-bit lazy accumulators: products
+// of two residues < q are summed without reduction for as many terms as fit in
+// 64 bits (all of them for 24-bit primes), then reduced once with a mulhi by
+// floor(2^64/q).  One launch covers every limb (the reference launches per limb).
+#include "common.h"
+#include "modarith.h"
+
+#include <algorithm>
+
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
+
+template <typename W, int OP, bool BCAST, int VN>
+__global__ void elementwise_kernel(W *__restrict__ out, const W *__restrict__ a, const W *__restrict__ b,
+                                   const LimbConst *__restrict__ limbs, uint32_t L, uint32_t logN,
+                                   size_t words_per_poly, size_t total_vecs) {
+    size_t v = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (; v < total_vecs; v += stride) {
+        const size_t w0 = v * VN;
+        const uint32_t limb = static_cast<uint32_t>((w0 >> logN) % L);
+        const LimbConst lc = limbs[limb];
+        const W q = static_cast<W>(lc.q);
+        const size_t bw0 = BCAST ? (w0 % words_per_poly) : w0;
+        W av[VN], bv[VN], ov[VN];
+        if (VN == 1) {
+            av[0] = a[w0];
+            bv[0] = b[bw0];
+        } else {
+            typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
+            *reinterpret_cast<V16 *>(av) = *reinterpret_cast<const V16 *>(a + w0);
+            *reinterpret_cast<V16 *>(bv) = *reinterpret_cast<const V16 *>(b + bw0);
+        }
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            if (OP == OP_ADD) ov[j] = add_mod<W>(av[j], bv[j], q);
+            else if (OP == OP_SUB) ov[j] = sub_mod<W>(av[j], bv[j], q);
+            else ov[j] = mul_mod<W>(av[j], bv[j], q, lc.mu, lc.kbits);
+        }
+        if (VN == 1) {
+            out[w0] = ov[0];
+        } else {
+            typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
+            *reinterpret_cast<V16 *>(out + w0) = *reinterpret_cast<const V16 *>(ov);
+        }
+    }
+}
+
+template <typename W>
+__global__ void equal_kernel(const W *__restrict__ a, const W *__restrict__ b, size_t total, int *__restrict__ diff) {
+    size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    int d = 0;
+    for (; i < total; i += stride) d |= (a[i] != b[i]);
+    if (d) atomicOr(diff, 1);
+}
+
+// ---- matrix product ---------------------------------------------------------------------
+template <typename W, int TR, int TC, int SV>
+__global__ void __launch_bounds__(256)
+    matmul_kernel(W *__restrict__ C, const W *__restrict__ A, const W *__restrict__ B,
+                  const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L,
+                  uint32_t N, uint32_t col_tiles) {
+    const uint32_t limb = blockIdx.z;
+    const uint32_t rt = blockIdx.y / col_tiles, ct = blockIdx.y - rt * col_tiles;
+    const uint32_t r0 = rt * TR, c0 = ct * TC;
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * SV;
+    if (i >= N) return;
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q);
+    typedef typename std::conditional<SV == 4, uint4, typename std::conditional<SV == 2, ulonglong2, W>::type>::type VT;
+    static_assert(sizeof(VT) == sizeof(W) * SV, "vector width");
+
+    const size_t strideA = static_cast<size_t>(L) * N;  // words between consecutive polys
+    // clamp out-of-range tile rows/cols to a valid entry; their results are never stored
+    size_t a_off[TR], b_off[TC];
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        uint32_t rr = min(r0 + r, rows - 1);
+        a_off[r] = (static_cast<size_t>(rr) * inner * L + limb) * N + i;
+    }
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        uint32_t cc = min(c0 + c, cols - 1);
+        b_off[c] = (static_cast<size_t>(cc) * L + limb) * N + i;
+    }
+    const size_t strideBk = static_cast<size_t>(cols) * L * N;
+
+    if constexpr (sizeof(W) == 4) {
+        uint64_t acc[TR][TC][SV];
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+            for (int c = 0; c < TC; ++c)
+#pragma unroll
+                for (int s = 0; s < SV; ++s) acc[r][c][s] = 0;
+        const uint32_t lazy = lc.lazy_terms;
+        uint32_t pending = 0;
+        for (uint32_t k = 0; k < inner; ++k) {
+            W av[TR][SV], bv[TC][SV];
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+                *reinterpret_cast<VT *>(av[r]) = *reinterpret_cast<const VT *>(A + a_off[r] + k * strideA);
+#pragma unroll
+            for (int c = 0; c < TC; ++c)
+                *reinterpret_cast<VT *>(bv[c]) = *reinterpret_cast<const VT *>(B + b_off[c] + k * strideBk);
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int c = 0; c < TC; ++c)
+#pragma unroll
+                    for (int s = 0; s < SV; ++s)
+                        acc[r][c][s] += static_cast<uint64_t>(av[r][s]) * static_cast<uint64_t>(bv[c][s]);
+            if (++pending == lazy) {
+                pending = 0;
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < TC; ++c)
+#pragma unroll
+                        for (int s = 0; s < SV; ++s) acc[r][c][s] = reduce_u64_sum(acc[r][c][s], q, lc.mu64);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (r0 + r >= rows) continue;
+#pragma unroll
+            for (int c = 0; c < TC; ++c) {
+                if (c0 + c >= cols) continue;
+                W o[SV];
+#pragma unroll
+                for (int s = 0; s < SV; ++s) o[s] = reduce_u64_sum(acc[r][c][s], q, lc.mu64);
+                *reinterpret_cast<VT *>(C + ((static_cast<size_t>(r0 + r) * cols + (c0 + c)) * L + limb) * N + i) =
+                    *reinterpret_cast<const VT *>(o);
+            }
+        }
+    } else {
+        W acc[TR][TC][SV];
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+            for (int c = 0; c < TC; ++c)
+#pragma unroll
+                for (int s = 0; s < SV; ++s) acc[r][c][s] = 0;
+        for (uint32_t k = 0; k < inner; ++k) {
+            W av[TR][SV], bv[TC][SV];
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+                *reinterpret_cast<VT *>(av[r]) = *reinterpret_cast<const VT *>(A + a_off[r] + k * strideA);
+#pragma unroll
+            for (int c = 0; c < TC; ++c)
+                *reinterpret_cast<VT *>(bv[c]) = *reinterpret_cast<const VT *>(B + b_off[c] + k * strideBk);
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int c = 0; c < TC; ++c)
+#pragma unroll
+                    for (int s = 0; s < SV; ++s)
+                        acc[r][c][s] =
+                            add_mod<W>(acc[r][c][s], mul_mod<W>(av[r][s], bv[c][s], q, lc.mu, lc.kbits), q);
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (r0 + r >= rows) continue;
+#pragma unroll
+            for (int c = 0; c < TC; ++c) {
+                if (c0 + c >= cols) continue;
+                *reinterpret_cast<VT *>(C + ((static_cast<size_t>(r0 + r) * cols + (c0 + c)) * L + limb) * N + i) =
+                    *reinterpret_cast<const VT *>(acc[r][c]);
+            }
+        }
+    }
+}
+
+template <typename W, int TR, int TC, int SV>
+static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    GpuContext *ctx = out->ctx;
+    const uint32_t rows = static_cast<uint32_t>(lhs->rows), inner = static_cast<uint32_t>(lhs->cols),
+                   cols = static_cast<uint32_t>(rhs->cols);
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(out)), N = static_cast<uint32_t>(ctx->N);
+    const uint32_t row_tiles = (rows + TR - 1) / TR, col_tiles = (cols + TC - 1) / TC;
+    const uint32_t threads = std::min<uint32_t>(256, std::max<uint32_t>(64, N / SV));
+    const uint32_t gx = (N / SV + threads - 1) / threads;
+    if (static_cast<uint64_t>(row_tiles) * col_tiles > 65535) return set_error("gpu_matrix_mul: matrix too large");
+    dim3 grid(gx, row_tiles * col_tiles, L);
+    hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV>), grid, dim3(threads), 0, ctx->stream,
+                       static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
+                       static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    GpuContext *ctx = out->ctx;
+    const size_t rows = lhs->rows, cols = rhs->cols;
+    const int N = ctx->N;
+    if (ctx->wide) {
+        if (N >= 2) {
+            if (rows >= 4) return launch_matmul_cfg<uint64_t, 4, 4, 2>(out, lhs, rhs);
+            if (rows >= 2) return launch_matmul_cfg<uint64_t, 2, 4, 2>(out, lhs, rhs);
+            return launch_matmul_cfg<uint64_t, 1, 4, 2>(out, lhs, rhs);
+        }
+        return launch_matmul_cfg<uint64_t, 1, 4, 1>(out, lhs, rhs);
+    }
+    if (N >= 4) {
+        if (rows >= 4) return launch_matmul_cfg<uint32_t, 4, 8, 1>(out, lhs, rhs);
+        if (rows >= 2) return launch_matmul_cfg<uint32_t, 2, 8, 4>(out, lhs, rhs);
+        if (cols >= 8) return launch_matmul_cfg<uint32_t, 1, 8, 4>(out, lhs, rhs);
+        return launch_matmul_cfg<uint32_t, 1, 4, 4>(out, lhs, rhs);
+    }
+    return launch_matmul_cfg<uint32_t, 1, 4, 1>(out, lhs, rhs);
+}
+
+// ---- host dispatch for element-wise ops ----------------------------------------------------------
+template <typename W, int OP, bool BCAST>
+static int launch_elementwise_typed(GpuMatrix *out, const GpuMatrix *a, const GpuMatrix *b) {
+    GpuContext *ctx = out->ctx;
+    const size_t words = matrix_words(out);
+    if (words == 0) return 0;
+    const size_t wpp = matrix_limbs(out) * static_cast<size_t>(ctx->N);
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
+    constexpr int VNATIVE = 16 / sizeof(W);
+    if (ctx->N >= VNATIVE) {
+        const size_t vecs = words / VNATIVE;
+        unsigned blocks = static_cast<unsigned>(std::min<size_t>((vecs + 255) / 256, 16384));
+        hipLaunchKernelGGL((elementwise_kernel<W, OP, BCAST, VNATIVE>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<W *>(out->data), static_cast<const W *>(a->data),
+                           static_cast<const W *>(b->data), ctx->d_limbs, L, ctx->logN, wpp, vecs);
+    } else {
+        unsigned blocks = static_cast<unsigned>(std::min<size_t>((words + 255) / 256, 16384));
+        hipLaunchKernelGGL((elementwise_kernel<W, OP, BCAST, 1>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<W *>(out->data), static_cast<const W *>(a->data),
+                           static_cast<const W *>(b->data), ctx->d_limbs, L, ctx->logN, wpp, words);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int OP, bool BCAST>
+static int launch_elementwise(GpuMatrix *out, const GpuMatrix *a, const GpuMatrix *b) {
+    if (ctx_activate(out->ctx)) return 1;
+    return out->ctx->wide ? launch_elementwise_typed<uint64_t, OP, BCAST>(out, a, b)
+                          : launch_elementwise_typed<uint32_t, OP, BCAST>(out, a, b);
+}
+
+// ---- ABI ---------------------------------------------------------------------------------------
+extern "C" int gpu_matrix_add(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    ABI_GUARD_BEGIN
+    if (matrix_check_same_shape(out, lhs, "gpu_matrix_add") || matrix_check_same_shape(lhs, rhs, "gpu_matrix_add"))
+        return 1;
+    int rc = launch_elementwise<OP_ADD, false>(out, lhs, rhs);
+    if (rc) return rc;
+    out->format = GPU_POLY_FORMAT_EVAL;  // quirk kept: MatrixArith.cu:2694
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_sub(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    ABI_GUARD_BEGIN
+    if (matrix_check_same_shape(out, lhs, "gpu_matrix_sub") || matrix_check_same_shape(lhs, rhs, "gpu_matrix_sub"))
+        return 1;
+    int rc = launch_elementwise<OP_SUB, false>(out, lhs, rhs);
+    if (rc) return rc;
+    out->format = GPU_POLY_FORMAT_EVAL;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_mul_scalar(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *scalar) {
+    ABI_GUARD_BEGIN
+    if (!scalar) return set_error("gpu_matrix_mul_scalar: null scalar");
+    if (matrix_check_same_shape(out, lhs, "gpu_matrix_mul_scalar")) return 1;
+    if (scalar->ctx != lhs->ctx || scalar->level != lhs->level)
+        return set_error("gpu_matrix_mul_scalar: context/level mismatch");
+    if (scalar->rows != 1 || scalar->cols != 1) return set_error("gpu_matrix_mul_scalar: scalar must be 1x1");
+    if (lhs->format != GPU_POLY_FORMAT_EVAL || scalar->format != GPU_POLY_FORMAT_EVAL)
+        return set_error("gpu_matrix_mul_scalar requires Eval format");
+    int rc = launch_elementwise<OP_MUL, true>(out, lhs, scalar);
+    if (rc) return rc;
+    out->format = GPU_POLY_FORMAT_EVAL;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    ABI_GUARD_BEGIN
+    if (!out || !lhs || !rhs) return set_error("gpu_matrix_mul: null matrix");
+    if (out->ctx != lhs->ctx || out->ctx != rhs->ctx) return set_error("gpu_matrix_mul: context mismatch");
+    if (out->level != lhs->level || out->level != rhs->level) return set_error("gpu_matrix_mul: level mismatch");
+    if (lhs->cols != rhs->rows || out->rows != lhs->rows || out->cols != rhs->cols)
+        return set_error("gpu_matrix_mul: shape mismatch");
+    if (lhs->format != GPU_POLY_FORMAT_EVAL || rhs->format != GPU_POLY_FORMAT_EVAL)
+        return set_error("gpu_matrix_mul requires Eval format");
+    if (out == lhs || out == rhs) return set_error("gpu_matrix_mul: output must not alias an input");
+    out->format = GPU_POLY_FORMAT_EVAL;
+    if (matrix_polys(out) == 0) return 0;
+    if (ctx_activate(out->ctx)) return 1;
+    if (lhs->cols == 0) {
+        HIP_TRY(hipMemsetAsync(out->data, 0, out->bytes, out->ctx->stream));
+        return 0;
+    }
+    return launch_matmul(out, lhs, rhs);
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_equal(const GpuMatrix *lhs, const GpuMatrix *rhs, int *out_equal) {
+    ABI_GUARD_BEGIN
+    if (!out_equal) return set_error("gpu_matrix_equal: null out_equal");
+    *out_equal = 0;
+    if (!lhs || !rhs) return set_error("gpu_matrix_equal: null matrix");
+    // mismatching ctx/level/shape/format is "not equal", not an error (MatrixArith.cu:2909-2980)
+    if (lhs->ctx != rhs->ctx || lhs->level != rhs->level || lhs->rows != rhs->rows || lhs->cols != rhs->cols ||
+        lhs->format != rhs->format)
+        return 0;
+    size_t words = matrix_words(lhs);
+    if (words == 0 || lhs == rhs) {
+        *out_equal = 1;
+        return 0;
+    }
+    GpuContext *ctx = lhs->ctx;
+    if (ctx_activate(ctx)) return 1;
+    void *flag = nullptr;
+    if (ctx_alloc(ctx, sizeof(int), &flag)) return 1;
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    unsigned blocks = static_cast<unsigned>(std::min<size_t>((words + 255) / 256, 8192));
+    if (ctx->wide)
+        hipLaunchKernelGGL(equal_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<const uint64_t *>(lhs->data), static_cast<const uint64_t *>(rhs->data), words,
+                           static_cast<int *>(flag));
+    else
+        hipLaunchKernelGGL(equal_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<const uint32_t *>(lhs->data), static_cast<const uint32_t *>(rhs->data), words,
+                           static_cast<int *>(flag));
+    HIP_TRY(hipGetLastError());
+    int diff = 0;
+    HIP_TRY(hipMemcpyAsync(&diff, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx_free(ctx, flag);
+    *out_equal = diff ? 0 : 1;
+    return 0;
+    ABI_GUARD_END
+}

@@ -1,0 +1,118 @@
+// common.h — private structures of libgpupoly (host side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <exception>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gpupoly.h"
+
+constexpr size_t GPUPOLY_MAX_LIMBS = 64;  // cuda/include/Runtime.cuh:51 of the reference
+
+// Per-limb constants, one array entry per prime, resident in HBM and read
+// through the scalar cache (uniform per workgroup).
+struct LimbConst {
+    uint64_t q;          // modulus
+    uint64_t mu;         // Barrett constant: floor(2^(2*kbits)/q)   (kbits = bits(q))
+    uint64_t mu64;       // floor(2^64/q) (u32 path: lazy 64-bit sum reduction)
+    uint64_t n_inv;      // N^-1 mod q
+    uint64_t n_inv_sh;   // Shoup companion of n_inv (2^32 or 2^64 scaled, by word width)
+    uint32_t kbits;      // bits(q)
+    uint32_t lazy_terms; // how many q^2-bounded products fit the accumulator
+};
+
+struct GpuContext {
+    int device = 0;
+    std::vector<int> gpu_ids;
+    uint32_t logN = 0;
+    int N = 0;
+    int level = 0;  // top level = limb_count-1
+    uint32_t dnum = 0;
+    int limb_count = 0;
+    bool wide = false;  // true: uint64_t residues
+    int word_bytes = 4;
+    uint32_t crt_bits = 0;  // max bit width over the moduli
+    std::vector<uint64_t> moduli;
+    hipStream_t stream = nullptr;
+    // device tables
+    LimbConst *d_limbs = nullptr;  // [limb_count]
+    void *d_tw_fwd = nullptr;      // [limb][N] words, fwd[bitrev(i)] = psi^i
+    void *d_tw_fwd_sh = nullptr;   // Shoup companions
+    void *d_tw_inv = nullptr;      // inv[bitrev(i)] = psi^-i
+    void *d_tw_inv_sh = nullptr;
+    uint64_t *d_garner = nullptr;  // [limb][limb] : inverse of q_j mod q_i for j<i
+    std::vector<uint64_t> garner_inv;  // host copy
+    std::vector<LimbConst> limbs;      // host copy
+    // bench timer
+    hipEvent_t timer_start = nullptr, timer_stop = nullptr;
+    std::vector<hipEvent_t> marks;  // lazily created timing marks
+    std::mutex mutex;
+    bool pool_ok = false;  // stream-ordered allocator usable
+};
+
+struct GpuMatrix {
+    GpuContext *ctx = nullptr;
+    int level = 0;
+    size_t rows = 0, cols = 0;
+    int format = GPU_POLY_FORMAT_EVAL;
+    void *data = nullptr;  // words [rows*cols][level+1][N]
+    size_t bytes = 0;
+};
+
+struct GpuEventSet {
+    std::vector<hipEvent_t> events;
+    int device = 0;
+    void *staging = nullptr;  // host-visible staging released after the wait
+    GpuContext *ctx = nullptr;
+    void *dev_staging = nullptr;
+};
+
+struct GpuP1CovarianceCache {
+    GpuContext *ctx = nullptr;
+    int level = 0;
+    size_t d = 0, m = 0, n = 0;
+    double sigma = 0, s = 0, dgg_stddev = 0;
+    double *sqrt_var = nullptr;      // [coeff][row]
+    double *update_coeff = nullptr;  // [coeff][sampled_row][updated_row]
+};
+
+// ---- error plumbing ---------------------------------------------------------
+int set_error(const char *msg);
+int set_error(const std::string &msg);
+int set_error(hipError_t err, const char *what);
+
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) return set_error(_e, #expr);     \
+    } while (0)
+
+// every extern "C" body is wrapped so no exception crosses the ABI
+#define ABI_GUARD_BEGIN try {
+#define ABI_GUARD_END                                                         \
+    }                                                                         \
+    catch (const std::exception &e) { return set_error(e.what()); }           \
+    catch (...) { return set_error("unknown exception in libgpupoly"); }
+
+// ---- helpers ------------------------------------------------------------------
+inline size_t matrix_polys(const GpuMatrix *m) { return m->rows * m->cols; }
+inline size_t matrix_limbs(const GpuMatrix *m) { return static_cast<size_t>(m->level) + 1; }
+inline size_t matrix_words(const GpuMatrix *m) { return matrix_polys(m) * matrix_limbs(m) * static_cast<size_t>(m->ctx->N); }
+
+int ctx_activate(const GpuContext *ctx);                   // hipSetDevice
+int ctx_alloc(GpuContext *ctx, size_t bytes, void **out);  // stream-ordered
+void ctx_free(GpuContext *ctx, void *ptr);                 // stream-ordered
+int matrix_check_same_shape(const GpuMatrix *a, const GpuMatrix *b, const char *who);
+
+// internal launchers shared across translation units
+int launch_ntt(GpuContext *ctx, void *data, size_t vectors, int limbs_per_poly, bool inverse);
+int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
+int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,
+                      size_t src_col, size_t rows, size_t cols, bool add);
+int launch_scatter_i64(GpuMatrix *out, const int64_t *vals);  // int64 [poly][N] -> residues in every limb

@@ -1,0 +1,405 @@
+// matrix.hip — matrix storage, block copies and host<->device RNS marshalling.
+// Replaces cuda/src/matrix/MatrixData.cu and the RNS-batch half of MatrixSerde.cu
+// (reference ABI: cuda/include/matrix/MatrixData.cuh:10-27,
+//  cuda/include/matrix/MatrixSerde.cuh:10-33).
+//
+// Device layout: one allocation per matrix, words [poly][limb][N] with
+// poly = row*cols + col.  A poly (all limbs) is contiguous, so a row segment
+// of a sub-block is one contiguous run and the host wire layout
+// ([poly][limb][N] u64, src/poly/dcrt/gpu.rs:758-788) maps 1:1 onto it.
+#include "common.h"
+#include "modarith.h"
+
+#include <algorithm>
+
+// ---- kernels ------------------------------------------------------------------------
+
+// host-order u64 staging -> device words (narrowing when W = uint32_t)
+template <typename W>
+__global__ void unpack_rns_kernel(const uint64_t *__restrict__ src, W *__restrict__ dst, size_t words_per_poly_dst,
+                                  size_t words_per_poly_src, size_t total) {
+    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (; idx < total; idx += stride) {
+        size_t poly = idx / words_per_poly_dst;
+        size_t w = idx - poly * words_per_poly_dst;
+        dst[idx] = static_cast<W>(src[poly * words_per_poly_src + w]);
+    }
+}
+
+template <typename W>
+__global__ void pack_rns_kernel(const W *__restrict__ src, uint64_t *__restrict__ dst, size_t words_per_poly_src,
+                                size_t words_per_poly_dst, size_t total) {
+    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (; idx < total; idx += stride) {
+        size_t poly = idx / words_per_poly_src;
+        size_t w = idx - poly * words_per_poly_src;
+        dst[poly * words_per_poly_dst + w] = static_cast<uint64_t>(src[idx]);
+    }
+}
+
+// constant coefficient (index 0) of every limb of every poly -> u64 words
+template <typename W>
+__global__ void const_coeff_kernel(const W *__restrict__ src, uint64_t *__restrict__ dst, size_t polys, size_t limbs,
+                                   size_t N, size_t words_per_poly_dst) {
+    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= polys * limbs) return;
+    size_t poly = idx / limbs, l = idx - poly * limbs;
+    dst[poly * words_per_poly_dst + l] = static_cast<uint64_t>(src[(poly * limbs + l) * N]);
+}
+
+// rectangular block copy / accumulate; one blockIdx.y per (row, col) entry of the block
+template <typename W, bool ADD>
+__global__ void block_rect_kernel(W *__restrict__ dst, const W *__restrict__ src, const LimbConst *__restrict__ limbs,
+                                  size_t dst_cols, size_t src_cols, size_t dst_row, size_t dst_col, size_t src_row,
+                                  size_t src_col, size_t cols, size_t words_per_poly, uint32_t N) {
+    size_t entry = blockIdx.y;
+    size_t r = entry / cols, c = entry - r * cols;
+    const W *s = src + ((src_row + r) * src_cols + (src_col + c)) * words_per_poly;
+    W *d = dst + ((dst_row + r) * dst_cols + (dst_col + c)) * words_per_poly;
+    for (size_t w = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < words_per_poly;
+         w += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        if (ADD) {
+            W q = static_cast<W>(limbs[w / N].q);
+            d[w] = add_mod<W>(d[w], s[w], q);
+        } else {
+            d[w] = s[w];
+        }
+    }
+}
+
+// int64 [poly][N] -> residues in every limb of `out`
+template <typename W>
+__global__ void scatter_i64_kernel(W *__restrict__ dst, const int64_t *__restrict__ vals,
+                                   const LimbConst *__restrict__ limbs, size_t polys, uint32_t L, uint32_t N) {
+    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t total = polys * N;
+    if (idx >= total) return;
+    size_t poly = idx / N;
+    uint32_t i = static_cast<uint32_t>(idx - poly * N);
+    int64_t v = vals[idx];
+    for (uint32_t l = 0; l < L; ++l) {
+        W q = static_cast<W>(limbs[l].q);
+        dst[(poly * L + l) * N + i] = signed_to_residue<W>(v, q);
+    }
+}
+
+// ---- helpers ---------------------------------------------------------------------------
+int matrix_check_same_shape(const GpuMatrix *a, const GpuMatrix *b, const char *who) {
+    if (!a || !b) return set_error(std::string(who) + ": null matrix");
+    if (a->ctx != b->ctx) return set_error(std::string(who) + ": context mismatch");
+    if (a->level != b->level) return set_error(std::string(who) + ": level mismatch");
+    if (a->rows != b->rows || a->cols != b->cols) return set_error(std::string(who) + ": shape mismatch");
+    return 0;
+}
+
+static inline unsigned grid_for(size_t total, unsigned threads, unsigned cap = 8192) {
+    size_t blocks = (total + threads - 1) / threads;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return static_cast<unsigned>(blocks);
+}
+
+int launch_scatter_i64(GpuMatrix *out, const int64_t *vals) {
+    GpuContext *ctx = out->ctx;
+    size_t polys = matrix_polys(out);
+    if (polys == 0) return 0;
+    size_t total = polys * ctx->N;
+    unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+    uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
+    if (ctx->wide)
+        hipLaunchKernelGGL(scatter_i64_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<uint64_t *>(out->data), vals, ctx->d_limbs, polys, L, (uint32_t)ctx->N);
+    else
+        hipLaunchKernelGGL(scatter_i64_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<uint32_t *>(out->data), vals, ctx->d_limbs, polys, L, (uint32_t)ctx->N);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,
+                      size_t src_col, size_t rows, size_t cols, bool add) {
+    const char *who = add ? "gpu_matrix_add_block" : "gpu_matrix_copy_block";
+    if (!out || !src) return set_error(std::string(who) + ": null matrix");
+    if (out->ctx != src->ctx) return set_error(std::string(who) + ": context mismatch");
+    if (out->level != src->level) return set_error(std::string(who) + ": level mismatch");
+    if (src_row + rows > src->rows || src_col + cols > src->cols)
+        return set_error(std::string(who) + ": source block out of bounds");
+    if (dst_row + rows > out->rows || dst_col + cols > out->cols)
+        return set_error(std::string(who) + ": destination block out of bounds");
+    // quirk kept from the reference: the whole destination is retagged with the
+    // source's format even for a partial block (MatrixData.cu:519,531,558)
+    out->format = src->format;
+    if (rows == 0 || cols == 0) return 0;
+    GpuContext *ctx = out->ctx;
+    if (ctx_activate(ctx)) return 1;
+    size_t wpp = matrix_limbs(out) * static_cast<size_t>(ctx->N);
+    if (!add) {
+        size_t wb = static_cast<size_t>(ctx->word_bytes);
+        const char *s = static_cast<const char *>(src->data) + (src_row * src->cols + src_col) * wpp * wb;
+        char *d = static_cast<char *>(out->data) + (dst_row * out->cols + dst_col) * wpp * wb;
+        if (out == src) {
+            // overlapping self-copy: go through the kernel only when disjoint is not guaranteed
+            // (hipMemcpy2D has undefined overlap semantics); use a temp
+            void *tmp = nullptr;
+            size_t row_bytes = cols * wpp * wb;
+            if (ctx_alloc(ctx, rows * row_bytes, &tmp)) return 1;
+            HIP_TRY(hipMemcpy2DAsync(tmp, row_bytes, s, src->cols * wpp * wb, row_bytes, rows,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, tmp, row_bytes, row_bytes, rows,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+            ctx_free(ctx, tmp);
+            return 0;
+        }
+        if (rows == 1 || (cols == src->cols && cols == out->cols)) {
+            HIP_TRY(hipMemcpyAsync(d, s, rows * cols * wpp * wb, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, s, src->cols * wpp * wb, cols * wpp * wb, rows,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return 0;
+    }
+    size_t entries = rows * cols;
+    // blockIdx.y is limited to 65535: chunk over row groups
+    size_t rows_per_launch = std::max<size_t>(1, 65535 / cols);
+    if (cols > 65535) return set_error(std::string(who) + ": block too wide");
+    (void)entries;
+    unsigned gx = grid_for(wpp, 256, 64);
+    for (size_t r0 = 0; r0 < rows; r0 += rows_per_launch) {
+        size_t rr = std::min(rows_per_launch, rows - r0);
+        dim3 grid(gx, static_cast<unsigned>(rr * cols));
+        if (ctx->wide)
+            hipLaunchKernelGGL((block_rect_kernel<uint64_t, true>), grid, dim3(256), 0, ctx->stream,
+                               static_cast<uint64_t *>(out->data), static_cast<const uint64_t *>(src->data),
+                               ctx->d_limbs, out->cols, src->cols, dst_row + r0, dst_col, src_row + r0, src_col, cols,
+                               wpp, (uint32_t)ctx->N);
+        else
+            hipLaunchKernelGGL((block_rect_kernel<uint32_t, true>), grid, dim3(256), 0, ctx->stream,
+                               static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(src->data),
+                               ctx->d_limbs, out->cols, src->cols, dst_row + r0, dst_col, src_row + r0, src_col, cols,
+                               wpp, (uint32_t)ctx->N);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- ABI: storage -------------------------------------------------------------------------
+extern "C" int gpu_matrix_create(GpuContext *ctx, int level, size_t rows, size_t cols, int format, GpuMatrix **out) {
+    ABI_GUARD_BEGIN
+    if (!out) return set_error("gpu_matrix_create: null out");
+    *out = nullptr;
+    if (!ctx) return set_error("gpu_matrix_create: null context");
+    if (level < 0 || level > ctx->level) return set_error("gpu_matrix_create: invalid level");
+    if (format != GPU_POLY_FORMAT_COEFF && format != GPU_POLY_FORMAT_EVAL)
+        return set_error("gpu_matrix_create: invalid format");
+    if (ctx_activate(ctx)) return 1;
+    GpuMatrix *m = new GpuMatrix();
+    m->ctx = ctx;
+    m->level = level;
+    m->rows = rows;
+    m->cols = cols;
+    m->format = format;
+    m->bytes = matrix_words(m) * static_cast<size_t>(ctx->word_bytes);
+    if (m->bytes) {
+        if (ctx_alloc(ctx, m->bytes, &m->data)) {
+            delete m;
+            return 1;
+        }
+    }
+    *out = m;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" void gpu_matrix_destroy(GpuMatrix *mat) {
+    if (!mat) return;
+    if (mat->data) {
+        (void)hipSetDevice(mat->ctx->device);
+        ctx_free(mat->ctx, mat->data);  // stream-ordered: in-flight kernels finish first
+    }
+    delete mat;
+}
+
+extern "C" int gpu_matrix_copy(GpuMatrix *dst, const GpuMatrix *src) {
+    ABI_GUARD_BEGIN
+    if (matrix_check_same_shape(dst, src, "gpu_matrix_copy")) return 1;
+    dst->format = src->format;
+    if (dst->bytes == 0 || dst == src) return 0;
+    if (ctx_activate(dst->ctx)) return 1;
+    HIP_TRY(hipMemcpyAsync(dst->data, src->data, dst->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col,
+                                     size_t src_row, size_t src_col, size_t rows, size_t cols) {
+    ABI_GUARD_BEGIN
+    return launch_copy_block(out, src, dst_row, dst_col, src_row, src_col, rows, cols, false);
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_add_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col,
+                                    size_t src_row, size_t src_col, size_t rows, size_t cols) {
+    ABI_GUARD_BEGIN
+    return launch_copy_block(out, src, dst_row, dst_col, src_row, src_col, rows, cols, true);
+    ABI_GUARD_END
+}
+
+extern "C" int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, size_t *out_bytes) {
+    if (!mat || !out_ptr || !out_bytes) return set_error("gpupoly_matrix_device_ptr: null argument");
+    *out_ptr = mat->data;
+    *out_bytes = mat->bytes;
+    return 0;
+}
+
+// ---- ABI: RNS batch load/store (MatrixSerde.cu:566-924 behaviour) -----------------------------
+static int make_event_set(GpuContext *ctx, GpuEventSet **out_events, void *dev_staging) {
+    GpuEventSet *set = new GpuEventSet();
+    set->device = ctx->device;
+    set->ctx = ctx;
+    set->dev_staging = nullptr;
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        delete set;
+        return set_error(e, "hipEventCreate");
+    }
+    e = hipEventRecord(ev, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        delete set;
+        return set_error(e, "hipEventRecord");
+    }
+    set->events.push_back(ev);
+    if (dev_staging) ctx_free(ctx, dev_staging);  // stream-ordered, after the kernels that read it
+    if (out_events) {
+        *out_events = set;
+    } else {
+        (void)hipEventSynchronize(ev);
+        (void)hipEventDestroy(ev);
+        delete set;
+    }
+    return 0;
+}
+
+extern "C" int gpu_matrix_load_rns_batch(GpuMatrix *mat, const uint8_t *bytes, size_t bytes_per_poly, int format,
+                                         GpuEventSet **out_events) {
+    ABI_GUARD_BEGIN
+    if (out_events) *out_events = nullptr;
+    if (!mat) return set_error("gpu_matrix_load_rns_batch: null matrix");
+    if (format != GPU_POLY_FORMAT_COEFF && format != GPU_POLY_FORMAT_EVAL)
+        return set_error("gpu_matrix_load_rns_batch: invalid format");
+    GpuContext *ctx = mat->ctx;
+    size_t polys = matrix_polys(mat);
+    size_t wpp = matrix_limbs(mat) * static_cast<size_t>(ctx->N);
+    if (polys == 0) {
+        mat->format = format;
+        return 0;
+    }
+    if (!bytes) return set_error("gpu_matrix_load_rns_batch: null bytes");
+    if (bytes_per_poly % 8 != 0 || bytes_per_poly < wpp * 8)
+        return set_error("gpu_matrix_load_rns_batch: bytes_per_poly must be a multiple of 8 and >= (level+1)*N*8");
+    if (ctx_activate(ctx)) return 1;
+    size_t src_wpp = bytes_per_poly / 8;
+    // chunked staging keeps the transient footprint bounded for multi-GB matrices
+    const size_t max_stage_bytes = size_t(512) << 20;
+    size_t polys_per_chunk = std::max<size_t>(1, max_stage_bytes / bytes_per_poly);
+    polys_per_chunk = std::min(polys_per_chunk, polys);
+    void *stage = nullptr;
+    if (ctx_alloc(ctx, polys_per_chunk * bytes_per_poly, &stage)) return 1;
+    for (size_t p0 = 0; p0 < polys; p0 += polys_per_chunk) {
+        size_t pc = std::min(polys_per_chunk, polys - p0);
+        HIP_TRY(hipMemcpyAsync(stage, bytes + p0 * bytes_per_poly, pc * bytes_per_poly, hipMemcpyHostToDevice,
+                               ctx->stream));
+        size_t total = pc * wpp;
+        unsigned blocks = grid_for(total, 256);
+        if (ctx->wide)
+            hipLaunchKernelGGL(unpack_rns_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<const uint64_t *>(stage), static_cast<uint64_t *>(mat->data) + p0 * wpp,
+                               wpp, src_wpp, total);
+        else
+            hipLaunchKernelGGL(unpack_rns_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<const uint64_t *>(stage), static_cast<uint32_t *>(mat->data) + p0 * wpp,
+                               wpp, src_wpp, total);
+        HIP_TRY(hipGetLastError());
+    }
+    mat->format = format;  // "just retags" 
+    return make_event_set(ctx, out_events, stage);
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_out, size_t bytes_per_poly, int format,
+                                          GpuEventSet **out_events) {
+    ABI_GUARD_BEGIN
+    if (out_events) *out_events = nullptr;
+    if (!mat) return set_error("gpu_matrix_store_rns_batch: null matrix");
+    GpuContext *ctx = mat->ctx;
+    size_t polys = matrix_polys(mat);
+    size_t wpp = matrix_limbs(mat) * static_cast<size_t>(ctx->N);
+    if (polys == 0) return 0;
+    if (!bytes_out) return set_error("gpu_matrix_store_rns_batch: null output");
+    if (format != mat->format)
+        return set_error("gpu_matrix_store_rns_batch: format conversion is not supported; convert the matrix first");
+    if (bytes_per_poly % 8 != 0 || bytes_per_poly < wpp * 8)
+        return set_error("gpu_matrix_store_rns_batch: bytes_per_poly must be a multiple of 8 and >= (level+1)*N*8");
+    if (ctx_activate(ctx)) return 1;
+    size_t dst_wpp = bytes_per_poly / 8;
+    const size_t max_stage_bytes = size_t(512) << 20;
+    size_t polys_per_chunk = std::max<size_t>(1, max_stage_bytes / bytes_per_poly);
+    polys_per_chunk = std::min(polys_per_chunk, polys);
+    void *stage = nullptr;
+    if (ctx_alloc(ctx, polys_per_chunk * bytes_per_poly, &stage)) return 1;
+    if (dst_wpp != wpp) HIP_TRY(hipMemsetAsync(stage, 0, polys_per_chunk * bytes_per_poly, ctx->stream));
+    for (size_t p0 = 0; p0 < polys; p0 += polys_per_chunk) {
+        size_t pc = std::min(polys_per_chunk, polys - p0);
+        size_t total = pc * wpp;
+        unsigned blocks = grid_for(total, 256);
+        if (ctx->wide)
+            hipLaunchKernelGGL(pack_rns_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<const uint64_t *>(mat->data) + p0 * wpp, static_cast<uint64_t *>(stage), wpp,
+                               dst_wpp, total);
+        else
+            hipLaunchKernelGGL(pack_rns_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<const uint32_t *>(mat->data) + p0 * wpp, static_cast<uint64_t *>(stage), wpp,
+                               dst_wpp, total);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(bytes_out + p0 * bytes_per_poly, stage, pc * bytes_per_poly, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    }
+    return make_event_set(ctx, out_events, stage);
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t *words_out, size_t words_per_poly,
+                                                  GpuEventSet **out_events) {
+    ABI_GUARD_BEGIN
+    if (out_events) *out_events = nullptr;
+    if (!mat) return set_error("gpu_matrix_store_const_coeff_batch: null matrix");
+    GpuContext *ctx = mat->ctx;
+    size_t polys = matrix_polys(mat);
+    size_t L = matrix_limbs(mat);
+    if (polys == 0) return 0;
+    if (!words_out) return set_error("gpu_matrix_store_const_coeff_batch: null output");
+    if (mat->format != GPU_POLY_FORMAT_COEFF)
+        return set_error("gpu_matrix_store_const_coeff_batch requires Coeff format");
+    if (words_per_poly < L) return set_error("gpu_matrix_store_const_coeff_batch: words_per_poly < limb count");
+    if (ctx_activate(ctx)) return 1;
+    void *stage = nullptr;
+    size_t bytes = polys * words_per_poly * 8;
+    if (ctx_alloc(ctx, bytes, &stage)) return 1;
+    if (words_per_poly != L) HIP_TRY(hipMemsetAsync(stage, 0, bytes, ctx->stream));
+    unsigned blocks = static_cast<unsigned>((polys * L + 255) / 256);
+    if (ctx->wide)
+        hipLaunchKernelGGL(const_coeff_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<const uint64_t *>(mat->data), static_cast<uint64_t *>(stage), polys, L,
+                           (size_t)ctx->N, words_per_poly);
+    else
+        hipLaunchKernelGGL(const_coeff_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           static_cast<const uint32_t *>(mat->data), static_cast<uint64_t *>(stage), polys, L,
+                           (size_t)ctx->N, words_per_poly);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(words_out, stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return make_event_set(ctx, out_events, stage);
+    ABI_GUARD_END
+}

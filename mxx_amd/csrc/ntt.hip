@@ -1,0 +1,415 @@
+// ntt.hip — negacyclic NTT / INTT over Z_q[x]/(x^N+1), one workgroup per
+// (polynomial, RNS limb) with the whole residue vector resident in LDS.
+//
+// Convention = the reference CPU path's (OpenFHE), restated in-tree by the
+// reference at src/gadgets/ntt/mod.rs:189-198,288-392:
+//   forward  : Cooley-Tukey, natural-order input -> bit-reversed evaluations,
+//              stage m = 2^s uses fwd[m+i] for group i (fwd[bitrev(j)] = psi^j)
+//   inverse  : Gentleman-Sande with inv[m+i], then * N^-1.
+// It replaces gpu_matrix_ntt_all / gpu_matrix_intt_all of
+// cuda/src/matrix/MatrixNTT.cu:787-811 (2 + log2 N launches and ~17 HBM round
+// trips per transform there; one launch and one HBM round trip here).
+//
+// Structure of the LDS kernel (LOGN stages split into passes of <= LOGR stages):
+//   HBM --16 B/lane coalesced--> LDS | pass 0 | pass 1 | ... | --> HBM
+// In each pass a thread pulls 2^LOGR residues that form closed butterfly
+// networks into registers, runs up to LOGR radix-2 stages on them with Shoup
+// multiplications (twiddle and its companion floor(w*2^W/q) from an L2-resident
+// table), and puts them back in place; one barrier per pass.
+#include "common.h"
+#include "modarith.h"
+
+#include <atomic>
+#include <cstdlib>
+
+template <typename W>
+struct Vec16;
+template <>
+struct Vec16<uint32_t> {
+    typedef uint4 type;
+    static constexpr int n = 4;
+};
+template <>
+struct Vec16<uint64_t> {
+    typedef ulonglong2 type;
+    static constexpr int n = 2;
+};
+
+// LDS index padding: +4 words per 32 and +16 words per 512 keeps the strided pass
+// reads (stride 16/512 words) and the contiguous 16-byte reads mostly conflict-free.
+__device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + ((e >> 5) << 2) + ((e >> 9) << 4); }
+static inline size_t lds_padded_words(size_t n) { return n + ((n >> 5) << 2) + ((n >> 9) << 4) + 16; }
+
+template <typename W, int C, bool INV>
+__device__ __forceinline__ void butterfly_network(W (&v)[1 << C], const W *__restrict__ tw,
+                                                  const W *__restrict__ tws, uint32_t bi, int s_p, W q) {
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int half = 1 << (C - k - 1);
+            const uint32_t tb = (1u << (s_p + k)) + (bi << k);
+#pragma unroll
+            for (int u = 0; u < (1 << C); ++u) {
+                if (u & half) continue;
+                const uint32_t idx = tb + (static_cast<uint32_t>(u) >> (C - k));
+                const W w = tw[idx], ws = tws[idx];
+                const W U = v[u];
+                const W V = mul_shoup<W>(v[u + half], w, ws, q);
+                v[u] = add_mod<W>(U, V, q);
+                v[u + half] = sub_mod<W>(U, V, q);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = C - 1; k >= 0; --k) {
+            const int half = 1 << (C - k - 1);
+            const uint32_t tb = (1u << (s_p + k)) + (bi << k);
+#pragma unroll
+            for (int u = 0; u < (1 << C); ++u) {
+                if (u & half) continue;
+                const uint32_t idx = tb + (static_cast<uint32_t>(u) >> (C - k));
+                const W w = tw[idx], ws = tws[idx];
+                const W U = v[u];
+                const W V = v[u + half];
+                v[u] = add_mod<W>(U, V, q);
+                v[u + half] = mul_shoup<W>(sub_mod<W>(U, V, q), w, ws, q);
+            }
+        }
+    }
+}
+
+// one pass over the LDS-resident vector: stages [S_P, S_P + C)
+template <typename W, int LOGN, int LOGR, int S_P, int C, bool INV>
+__device__ __forceinline__ void lds_pass(W *__restrict__ x, const W *__restrict__ tw, const W *__restrict__ tws, W q,
+                                         uint32_t tid) {
+    constexpr uint32_t B = 1u << (LOGN - S_P);  // sub-problem size at this pass
+    constexpr uint32_t S = B >> C;              // element stride inside a butterfly set
+    constexpr int G = 1 << (LOGR - C);          // sets per thread
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint32_t sigma = tid * G + g;
+        const uint32_t bi = sigma / S;
+        const uint32_t r = sigma - bi * S;
+        const uint32_t base = bi * B + r;
+        W v[1 << C];
+#pragma unroll
+        for (int u = 0; u < (1 << C); ++u) v[u] = x[lds_pad(base + S * u)];
+        butterfly_network<W, C, INV>(v, tw, tws, bi, S_P, q);
+#pragma unroll
+        for (int u = 0; u < (1 << C); ++u) x[lds_pad(base + S * u)] = v[u];
+    }
+}
+
+template <typename W, int LOGN, int LOGR, bool INV>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR))
+    ntt_lds_kernel(W *__restrict__ data, const W *__restrict__ tw_all, const W *__restrict__ tws_all,
+                   const LimbConst *__restrict__ limbs, uint32_t L) {
+    constexpr uint32_t N = 1u << LOGN;
+    constexpr uint32_t T = 1u << (LOGN - LOGR);
+    constexpr int P = (LOGN + LOGR - 1) / LOGR;
+    constexpr int CLAST = LOGN - (P - 1) * LOGR;
+    static_assert(P >= 2 && P <= 4, "pass count");
+    typedef typename Vec16<W>::type V16;
+    constexpr int VN = Vec16<W>::n;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W *x = reinterpret_cast<W *>(smem);
+
+    const uint32_t tid = threadIdx.x;
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const W q = static_cast<W>(limbs[limb].q);
+    const W *tw = tw_all + static_cast<size_t>(limb) * N;
+    const W *tws = tws_all + static_cast<size_t>(limb) * N;
+    W *g = data + vec * N;
+
+    // HBM -> LDS, 16 bytes per lane, fully coalesced
+#pragma unroll
+    for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
+        const uint32_t i = tid + jj * T;
+        V16 val = reinterpret_cast<const V16 *>(g)[i];
+        *reinterpret_cast<V16 *>(&x[lds_pad(i * VN)]) = val;
+    }
+    __syncthreads();
+
+    if (!INV) {
+        lds_pass<W, LOGN, LOGR, 0, LOGR, false>(x, tw, tws, q, tid);
+        __syncthreads();
+        if constexpr (P == 2) {
+            lds_pass<W, LOGN, LOGR, LOGR, CLAST, false>(x, tw, tws, q, tid);
+        } else if constexpr (P == 3) {
+            lds_pass<W, LOGN, LOGR, LOGR, LOGR, false>(x, tw, tws, q, tid);
+            __syncthreads();
+            lds_pass<W, LOGN, LOGR, 2 * LOGR, CLAST, false>(x, tw, tws, q, tid);
+        } else {
+            lds_pass<W, LOGN, LOGR, LOGR, LOGR, false>(x, tw, tws, q, tid);
+            __syncthreads();
+            lds_pass<W, LOGN, LOGR, 2 * LOGR, LOGR, false>(x, tw, tws, q, tid);
+            __syncthreads();
+            lds_pass<W, LOGN, LOGR, 3 * LOGR, CLAST, false>(x, tw, tws, q, tid);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
+            const uint32_t i = tid + jj * T;
+            V16 val = *reinterpret_cast<const V16 *>(&x[lds_pad(i * VN)]);
+            reinterpret_cast<V16 *>(g)[i] = val;
+        }
+    } else {
+        if constexpr (P == 2) {
+            lds_pass<W, LOGN, LOGR, LOGR, CLAST, true>(x, tw, tws, q, tid);
+        } else if constexpr (P == 3) {
+            lds_pass<W, LOGN, LOGR, 2 * LOGR, CLAST, true>(x, tw, tws, q, tid);
+            __syncthreads();
+            lds_pass<W, LOGN, LOGR, LOGR, LOGR, true>(x, tw, tws, q, tid);
+        } else {
+            lds_pass<W, LOGN, LOGR, 3 * LOGR, CLAST, true>(x, tw, tws, q, tid);
+            __syncthreads();
+            lds_pass<W, LOGN, LOGR, 2 * LOGR, LOGR, true>(x, tw, tws, q, tid);
+            __syncthreads();
+            lds_pass<W, LOGN, LOGR, LOGR, LOGR, true>(x, tw, tws, q, tid);
+        }
+        __syncthreads();
+        lds_pass<W, LOGN, LOGR, 0, LOGR, true>(x, tw, tws, q, tid);
+        __syncthreads();
+        const W ninv = static_cast<W>(limbs[limb].n_inv);
+        const W ninv_sh = static_cast<W>(limbs[limb].n_inv_sh);
+#pragma unroll
+        for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
+            const uint32_t i = tid + jj * T;
+            V16 val = *reinterpret_cast<const V16 *>(&x[lds_pad(i * VN)]);
+            W *e = reinterpret_cast<W *>(&val);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) e[j] = mul_shoup<W>(e[j], ninv, ninv_sh, q);
+            reinterpret_cast<V16 *>(g)[i] = val;
+        }
+    }
+}
+
+// Any logN whose vector fits LDS: one radix-2 stage per barrier (small / odd sizes).
+template <typename W, bool INV>
+__global__ void ntt_generic_kernel(W *__restrict__ data, const W *__restrict__ tw_all, const W *__restrict__ tws_all,
+                                   const LimbConst *__restrict__ limbs, uint32_t L, uint32_t logN) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W *x = reinterpret_cast<W *>(smem);
+    const uint32_t N = 1u << logN;
+    const uint32_t tid = threadIdx.x, T = blockDim.x;
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const W q = static_cast<W>(limbs[limb].q);
+    const W *tw = tw_all + static_cast<size_t>(limb) * N;
+    const W *tws = tws_all + static_cast<size_t>(limb) * N;
+    W *g = data + vec * N;
+    for (uint32_t i = tid; i < N; i += T) x[i] = g[i];
+    __syncthreads();
+    if (!INV) {
+        uint32_t logt = logN - 1;
+        for (uint32_t m = 1; m < N; m <<= 1, --logt) {
+            const uint32_t t = 1u << logt;
+            for (uint32_t b = tid; b < N / 2; b += T) {
+                const uint32_t i = b >> logt, j = b & (t - 1);
+                const uint32_t lo = (i << (logt + 1)) + j, hi = lo + t;
+                const W U = x[lo];
+                const W V = mul_shoup<W>(x[hi], tw[m + i], tws[m + i], q);
+                x[lo] = add_mod<W>(U, V, q);
+                x[hi] = sub_mod<W>(U, V, q);
+            }
+            __syncthreads();
+        }
+        for (uint32_t i = tid; i < N; i += T) g[i] = x[i];
+    } else {
+        uint32_t logt = 0;
+        for (uint32_t m = N >> 1; m >= 1; m >>= 1, ++logt) {
+            const uint32_t t = 1u << logt;
+            for (uint32_t b = tid; b < N / 2; b += T) {
+                const uint32_t i = b >> logt, j = b & (t - 1);
+                const uint32_t lo = (i << (logt + 1)) + j, hi = lo + t;
+                const W U = x[lo], V = x[hi];
+                x[lo] = add_mod<W>(U, V, q);
+                x[hi] = mul_shoup<W>(sub_mod<W>(U, V, q), tw[m + i], tws[m + i], q);
+            }
+            __syncthreads();
+        }
+        const W ninv = static_cast<W>(limbs[limb].n_inv);
+        const W ninv_sh = static_cast<W>(limbs[limb].n_inv_sh);
+        for (uint32_t i = tid; i < N; i += T) g[i] = mul_shoup<W>(x[i], ninv, ninv_sh, q);
+    }
+}
+
+// Vectors too large for LDS: one radix-2 stage per launch straight on HBM.
+template <typename W, bool INV>
+__global__ void ntt_stage_global_kernel(W *__restrict__ data, const W *__restrict__ tw_all,
+                                        const W *__restrict__ tws_all, const LimbConst *__restrict__ limbs, uint32_t L,
+                                        uint32_t logN, uint32_t m, uint32_t logt, size_t vectors) {
+    const size_t half = static_cast<size_t>(1) << (logN - 1);
+    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= vectors * half) return;
+    const size_t vec = idx >> (logN - 1);
+    const uint32_t b = static_cast<uint32_t>(idx & (half - 1));
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const W q = static_cast<W>(limbs[limb].q);
+    const size_t N = static_cast<size_t>(1) << logN;
+    const W *tw = tw_all + limb * N;
+    const W *tws = tws_all + limb * N;
+    W *x = data + vec * N;
+    const uint32_t t = 1u << logt;
+    const uint32_t i = b >> logt, j = b & (t - 1);
+    const uint32_t lo = (i << (logt + 1)) + j, hi = lo + t;
+    const W U = x[lo];
+    if (!INV) {
+        const W V = mul_shoup<W>(x[hi], tw[m + i], tws[m + i], q);
+        x[lo] = add_mod<W>(U, V, q);
+        x[hi] = sub_mod<W>(U, V, q);
+    } else {
+        const W V = x[hi];
+        x[lo] = add_mod<W>(U, V, q);
+        x[hi] = mul_shoup<W>(sub_mod<W>(U, V, q), tw[m + i], tws[m + i], q);
+    }
+}
+
+template <typename W>
+__global__ void ntt_scale_global_kernel(W *__restrict__ data, const LimbConst *__restrict__ limbs, uint32_t L,
+                                        uint32_t logN, size_t total) {
+    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t limb = static_cast<uint32_t>((idx >> logN) % L);
+    const W q = static_cast<W>(limbs[limb].q);
+    data[idx] = mul_shoup<W>(data[idx], static_cast<W>(limbs[limb].n_inv), static_cast<W>(limbs[limb].n_inv_sh), q);
+}
+
+// ---- host-side dispatch -------------------------------------------------------------------
+static constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+template <typename W, int LOGN, int LOGR, bool INV>
+static int launch_lds(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
+    auto kern = ntt_lds_kernel<W, LOGN, LOGR, INV>;
+    const size_t lds = lds_padded_words(size_t(1) << LOGN) * sizeof(W);
+    static std::atomic<uint64_t> configured_mask{0};
+    if (lds > 64 * 1024 && !(configured_mask.load() & (1ull << (ctx->device & 63)))) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        configured_mask.fetch_or(1ull << (ctx->device & 63));
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(vectors)), dim3(1u << (LOGN - LOGR)), lds, ctx->stream, data,
+                       static_cast<const W *>(INV ? ctx->d_tw_inv : ctx->d_tw_fwd),
+                       static_cast<const W *>(INV ? ctx->d_tw_inv_sh : ctx->d_tw_fwd_sh), ctx->d_limbs, L);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename W, bool INV>
+static int launch_generic(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
+    const uint32_t logN = ctx->logN;
+    const size_t N = size_t(1) << logN;
+    const size_t lds = N * sizeof(W);
+    auto kern = ntt_generic_kernel<W, INV>;
+    if (lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+    }
+    unsigned threads = static_cast<unsigned>(N / 2);
+    if (threads < 64) threads = 64;
+    if (threads > 512) threads = 512;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(vectors)), dim3(threads), lds, ctx->stream, data,
+                       static_cast<const W *>(INV ? ctx->d_tw_inv : ctx->d_tw_fwd),
+                       static_cast<const W *>(INV ? ctx->d_tw_inv_sh : ctx->d_tw_fwd_sh), ctx->d_limbs, L, logN);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename W, bool INV>
+static int launch_global(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
+    const uint32_t logN = ctx->logN;
+    const size_t half = size_t(1) << (logN - 1);
+    const size_t total = vectors * half;
+    const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+    const W *tw = static_cast<const W *>(INV ? ctx->d_tw_inv : ctx->d_tw_fwd);
+    const W *tws = static_cast<const W *>(INV ? ctx->d_tw_inv_sh : ctx->d_tw_fwd_sh);
+    if (!INV) {
+        uint32_t logt = logN - 1;
+        for (uint32_t m = 1; m < (1u << logN); m <<= 1, --logt) {
+            hipLaunchKernelGGL((ntt_stage_global_kernel<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, data, tw,
+                               tws, ctx->d_limbs, L, logN, m, logt, vectors);
+        }
+    } else {
+        uint32_t logt = 0;
+        for (uint32_t m = 1u << (logN - 1); m >= 1; m >>= 1, ++logt) {
+            hipLaunchKernelGGL((ntt_stage_global_kernel<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, data, tw,
+                               tws, ctx->d_limbs, L, logN, m, logt, vectors);
+        }
+        const size_t words = vectors << logN;
+        hipLaunchKernelGGL(ntt_scale_global_kernel<W>, dim3(static_cast<unsigned>((words + 255) / 256)), dim3(256), 0,
+                           ctx->stream, data, ctx->d_limbs, L, logN, words);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int ntt_path_override() {
+    // MXX_HIP_NTT_PATH = lds | generic | global  (tests exercise every path)
+    const char *env = std::getenv("MXX_HIP_NTT_PATH");
+    if (!env) return 0;
+    if (env[0] == 'l') return 1;
+    if (env[0] == 'g' && env[1] == 'e') return 2;
+    if (env[0] == 'g' && env[1] == 'l') return 3;
+    return 0;
+}
+
+template <typename W, bool INV>
+static int launch_ntt_typed(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
+    const uint32_t logN = ctx->logN;
+    const size_t N = size_t(1) << logN;
+    const int force = ntt_path_override();
+    const bool fits_generic = N * sizeof(W) <= kMaxLdsBytes && logN >= 1;
+    const bool fits_tuned = lds_padded_words(N) * sizeof(W) <= kMaxLdsBytes;
+    if (force == 3 || !fits_generic) return launch_global<W, INV>(ctx, data, vectors, L);
+    if (force != 2 && fits_tuned) {
+        switch (logN) {
+            case 10: return launch_lds<W, 10, 4, INV>(ctx, data, vectors, L);
+            case 11: return launch_lds<W, 11, 4, INV>(ctx, data, vectors, L);
+            case 12: return launch_lds<W, 12, 4, INV>(ctx, data, vectors, L);
+            case 13: return launch_lds<W, 13, 5, INV>(ctx, data, vectors, L);
+            case 14: return launch_lds<W, 14, 5, INV>(ctx, data, vectors, L);
+            case 15: return launch_lds<W, 15, 5, INV>(ctx, data, vectors, L);
+            default: break;
+        }
+    }
+    return launch_generic<W, INV>(ctx, data, vectors, L);
+}
+
+int launch_ntt(GpuContext *ctx, void *data, size_t vectors, int limbs_per_poly, bool inverse) {
+    if (vectors == 0) return 0;
+    if (vectors > 0x7fffffffull) return set_error("ntt: too many vectors for one launch");
+    const uint32_t L = static_cast<uint32_t>(limbs_per_poly);
+    if (ctx->wide) {
+        return inverse ? launch_ntt_typed<uint64_t, true>(ctx, static_cast<uint64_t *>(data), vectors, L)
+                       : launch_ntt_typed<uint64_t, false>(ctx, static_cast<uint64_t *>(data), vectors, L);
+    }
+    return inverse ? launch_ntt_typed<uint32_t, true>(ctx, static_cast<uint32_t *>(data), vectors, L)
+                   : launch_ntt_typed<uint32_t, false>(ctx, static_cast<uint32_t *>(data), vectors, L);
+}
+
+// ---- ABI (cuda/include/matrix/MatrixNTT.cuh:9-10): idempotent w.r.t. the format tag -------------
+extern "C" int gpu_matrix_ntt_all(GpuMatrix *mat) {
+    ABI_GUARD_BEGIN
+    if (!mat) return set_error("gpu_matrix_ntt_all: null matrix");
+    if (mat->format == GPU_POLY_FORMAT_EVAL) return 0;
+    if (ctx_activate(mat->ctx)) return 1;
+    int rc = launch_ntt(mat->ctx, mat->data, matrix_polys(mat) * matrix_limbs(mat), mat->level + 1, false);
+    if (rc) return rc;
+    mat->format = GPU_POLY_FORMAT_EVAL;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_intt_all(GpuMatrix *mat) {
+    ABI_GUARD_BEGIN
+    if (!mat) return set_error("gpu_matrix_intt_all: null matrix");
+    if (mat->format == GPU_POLY_FORMAT_COEFF) return 0;
+    if (ctx_activate(mat->ctx)) return 1;
+    int rc = launch_ntt(mat->ctx, mat->data, matrix_polys(mat) * matrix_limbs(mat), mat->level + 1, true);
+    if (rc) return rc;
+    mat->format = GPU_POLY_FORMAT_COEFF;
+    return 0;
+    ABI_GUARD_END
+}

@@ -1,0 +1,461 @@
+// runtime.hip — context, per-prime constants, events, device queries, errors.
+// Replaces cuda/src/Runtime.cu of the reference behind the same C ABI
+// (cuda/include/Runtime.cuh:20-44,108), re-designed for one HIP stream per
+// context and the OpenFHE NTT convention.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+typedef unsigned __int128 u128h;
+
+// ---- thread-local error string (Runtime.cu:16-27,817-820 behaviour) -----------
+static thread_local std::string g_last_error;
+
+int set_error(const char *msg) {
+    g_last_error = msg ? msg : "unknown error";
+    return 1;
+}
+int set_error(const std::string &msg) {
+    g_last_error = msg;
+    return 1;
+}
+int set_error(hipError_t err, const char *what) {
+    g_last_error = std::string(what ? what : "hip call") + ": " + hipGetErrorString(err);
+    (void)hipGetLastError();
+    return 1;
+}
+
+extern "C" const char *gpu_last_error(void) { return g_last_error.c_str(); }
+extern "C" int gpu_set_last_error(const char *msg) { return set_error(msg); }
+extern "C" const char *gpupoly_version(void) { return "gpupoly-mi355x 0.1 (gfx950)"; }
+
+// ---- host number theory ---------------------------------------------------------
+static inline uint64_t h_mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128h)a * b) % q); }
+static uint64_t h_powmod(uint64_t b, uint64_t e, uint64_t q) {
+    uint64_t r = 1 % q;
+    b %= q;
+    while (e) {
+        if (e & 1) r = h_mulmod(r, b, q);
+        b = h_mulmod(b, b, q);
+        e >>= 1;
+    }
+    return r;
+}
+static uint64_t h_invmod_prime(uint64_t a, uint64_t q) { return h_powmod(a % q, q - 2, q); }
+
+static bool h_is_prime(uint64_t n) {
+    static const uint64_t bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    if (n < 2) return false;
+    for (uint64_t b : bases)
+        if (n % b == 0) return n == b;
+    uint64_t d = n - 1;
+    int s = 0;
+    while (!(d & 1)) { d >>= 1; ++s; }
+    for (uint64_t b : bases) {
+        uint64_t x = h_powmod(b, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int r = 1; r < s; ++r) {
+            x = h_mulmod(x, x, n);
+            if (x == n - 1) { comp = false; break; }
+        }
+        if (comp) return false;
+    }
+    return true;
+}
+
+// psi = MIN over all primitive 2N-th roots of unity mod q — OpenFHE RootOfUnity(),
+// restated in-tree by the reference at src/gadgets/ntt/mod.rs:96-128.
+static uint64_t h_min_primitive_root(uint64_t q, uint64_t order) {
+    uint64_t qm1 = q - 1;
+    int v = __builtin_ctzll(qm1);
+    int want = __builtin_ctzll(order);
+    uint64_t odd = qm1 >> v;
+    uint64_t maximal = 0;
+    for (uint64_t x = 2; x < q; ++x) {
+        uint64_t r = h_powmod(x, odd, q);
+        if (h_powmod(r, 1ull << (v - 1), q) != 1) { maximal = r; break; }
+    }
+    uint64_t root = h_powmod(maximal, 1ull << (v - want), q);
+    uint64_t sq = h_mulmod(root, root, q);
+    uint64_t cur = root, best = root;
+    for (uint64_t i = 1; i < order / 2; ++i) {
+        cur = h_mulmod(cur, sq, q);
+        if (cur < best) best = cur;
+    }
+    return best;
+}
+
+static inline uint32_t h_bitrev(uint32_t x, uint32_t bits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+static inline uint32_t h_bits(uint64_t v) { return v ? 64 - (uint32_t)__builtin_clzll(v) : 0; }
+
+// ---- context ----------------------------------------------------------------------
+int ctx_activate(const GpuContext *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+int ctx_alloc(GpuContext *ctx, size_t bytes, void **out) {
+    *out = nullptr;
+    if (bytes == 0) return 0;
+    if (ctx->pool_ok) {
+        hipError_t e = hipMallocAsync(out, bytes, ctx->stream);
+        if (e == hipSuccess) return 0;
+        (void)hipGetLastError();
+    }
+    HIP_TRY(hipMalloc(out, bytes));
+    return 0;
+}
+
+void ctx_free(GpuContext *ctx, void *ptr) {
+    if (!ptr) return;
+    if (ctx->pool_ok) {
+        if (hipFreeAsync(ptr, ctx->stream) == hipSuccess) return;
+        (void)hipGetLastError();
+    }
+    // hipFree synchronises the device: still correct for in-flight work
+    (void)hipFree(ptr);
+}
+
+template <typename W>
+static int upload_tables(GpuContext *ctx, const std::vector<std::vector<uint64_t>> &fwd,
+                         const std::vector<std::vector<uint64_t>> &inv) {
+    const size_t N = ctx->N, L = ctx->limb_count;
+    const unsigned shift = sizeof(W) * 8;
+    std::vector<W> h_f(L * N), h_fs(L * N), h_i(L * N), h_is(L * N);
+    for (size_t l = 0; l < L; ++l) {
+        uint64_t q = ctx->moduli[l];
+        for (size_t j = 0; j < N; ++j) {
+            h_f[l * N + j] = (W)fwd[l][j];
+            h_fs[l * N + j] = (W)(((u128h)fwd[l][j] << shift) / q);
+            h_i[l * N + j] = (W)inv[l][j];
+            h_is[l * N + j] = (W)(((u128h)inv[l][j] << shift) / q);
+        }
+    }
+    size_t bytes = L * N * sizeof(W);
+    HIP_TRY(hipMalloc(&ctx->d_tw_fwd, bytes));
+    HIP_TRY(hipMalloc(&ctx->d_tw_fwd_sh, bytes));
+    HIP_TRY(hipMalloc(&ctx->d_tw_inv, bytes));
+    HIP_TRY(hipMalloc(&ctx->d_tw_inv_sh, bytes));
+    HIP_TRY(hipMemcpy(ctx->d_tw_fwd, h_f.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tw_fwd_sh, h_fs.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tw_inv, h_i.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tw_inv_sh, h_is.data(), bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void context_release(GpuContext *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_limbs) (void)hipFree(ctx->d_limbs);
+    if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
+    if (ctx->d_tw_fwd_sh) (void)hipFree(ctx->d_tw_fwd_sh);
+    if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);
+    if (ctx->d_tw_inv_sh) (void)hipFree(ctx->d_tw_inv_sh);
+    if (ctx->d_garner) (void)hipFree(ctx->d_garner);
+    if (ctx->timer_start) (void)hipEventDestroy(ctx->timer_start);
+    if (ctx->timer_stop) (void)hipEventDestroy(ctx->timer_stop);
+    for (hipEvent_t ev : ctx->marks)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, const uint64_t *moduli,
+                                  size_t moduli_len, const int *gpu_ids, size_t gpu_ids_len, GpuContext **out_ctx) {
+    ABI_GUARD_BEGIN
+    if (!out_ctx) return set_error("gpu_context_create: null out_ctx");
+    *out_ctx = nullptr;
+    if (!moduli || moduli_len == 0) return set_error("gpu_context_create: empty moduli");
+    if (moduli_len != static_cast<size_t>(L) + 1) return set_error("gpu_context_create: moduli_len must equal L+1");
+    if (moduli_len > GPUPOLY_MAX_LIMBS) return set_error("gpu_context_create: too many limbs");
+    if (!gpu_ids || gpu_ids_len == 0) return set_error("gpu_context_create: empty gpu_ids");
+    if (logN < 1 || logN > 17) return set_error("gpu_context_create: logN out of range [1,17]");
+    int dev_count = 0;
+    HIP_TRY(hipGetDeviceCount(&dev_count));
+    for (size_t i = 0; i < gpu_ids_len; ++i) {
+        if (gpu_ids[i] < 0 || gpu_ids[i] >= dev_count) return set_error("gpu_context_create: invalid gpu id");
+        for (size_t j = 0; j < i; ++j)
+            if (gpu_ids[j] == gpu_ids[i]) return set_error("gpu_context_create: duplicate gpu id");
+    }
+    const uint64_t N = 1ull << logN;
+    bool wide = false;
+    for (size_t i = 0; i < moduli_len; ++i) {
+        uint64_t q = moduli[i];
+        if (q < 3 || (q - 1) % (2 * N) != 0) return set_error("gpu_context_create: modulus must be = 1 (mod 2N)");
+        if (!h_is_prime(q)) return set_error("gpu_context_create: modulus is not prime");
+        if (q >> 62) return set_error("gpu_context_create: modulus must be < 2^62");
+        if (q >> 31) wide = true;
+        for (size_t j = 0; j < i; ++j)
+            if (moduli[j] == q) return set_error("gpu_context_create: duplicate modulus");
+    }
+
+    GpuContext *ctx = new GpuContext();
+    ctx->device = gpu_ids[0];
+    ctx->gpu_ids.assign(gpu_ids, gpu_ids + gpu_ids_len);
+    ctx->logN = logN;
+    ctx->N = static_cast<int>(N);
+    ctx->level = static_cast<int>(L);
+    ctx->dnum = dnum;
+    ctx->limb_count = static_cast<int>(moduli_len);
+    ctx->wide = wide;
+    ctx->word_bytes = wide ? 8 : 4;
+    ctx->moduli.assign(moduli, moduli + moduli_len);
+
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { delete ctx; return set_error(e, "hipSetDevice"); }
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return set_error(e, "hipStreamCreate"); }
+
+    // stream-ordered pool: keep freed blocks cached (env mirrors the reference's
+    // MXX_CUDA_MEMPOOL_RELEASE_THRESHOLD_BYTES, Runtime.cu:337-361)
+    {
+        int supported = 0;
+        if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, ctx->device) == hipSuccess &&
+            supported) {
+            hipMemPool_t pool;
+            if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess) {
+                uint64_t threshold = UINT64_MAX;
+                const char *env = std::getenv("MXX_HIP_MEMPOOL_RELEASE_THRESHOLD_BYTES");
+                if (!env) env = std::getenv("MXX_CUDA_MEMPOOL_RELEASE_THRESHOLD_BYTES");
+                if (env && *env) threshold = std::strtoull(env, nullptr, 10);
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+                ctx->pool_ok = true;
+            }
+        }
+        (void)hipGetLastError();
+        const char *nopool = std::getenv("MXX_HIP_DISABLE_MEMPOOL");
+        if (nopool && *nopool == '1') ctx->pool_ok = false;
+    }
+
+    // per-prime constants
+    std::vector<std::vector<uint64_t>> fwd(moduli_len), inv(moduli_len);
+    ctx->limbs.resize(moduli_len);
+    uint32_t crt_bits = 0;
+    for (size_t l = 0; l < moduli_len; ++l) {
+        uint64_t q = moduli[l];
+        uint64_t psi = h_min_primitive_root(q, 2 * N);
+        uint64_t ipsi = h_invmod_prime(psi, q);
+        fwd[l].resize(N);
+        inv[l].resize(N);
+        uint64_t p = 1, ip = 1;
+        for (uint64_t i = 0; i < N; ++i) {
+            uint32_t r = h_bitrev(static_cast<uint32_t>(i), logN);
+            fwd[l][r] = p;
+            inv[l][r] = ip;
+            p = h_mulmod(p, psi, q);
+            ip = h_mulmod(ip, ipsi, q);
+        }
+        LimbConst &lc = ctx->limbs[l];
+        lc.q = q;
+        lc.kbits = h_bits(q);
+        crt_bits = std::max(crt_bits, lc.kbits);
+        lc.mu = static_cast<uint64_t>((((u128h)1) << (2 * lc.kbits)) / q);
+        lc.mu64 = static_cast<uint64_t>((((u128h)1) << 64) / q);
+        lc.n_inv = h_invmod_prime(N % q, q);
+        lc.n_inv_sh = static_cast<uint64_t>(((u128h)lc.n_inv << (wide ? 64 : 32)) / q);
+        if (!wide) {
+            u128h q2 = (u128h)(q - 1) * (q - 1);
+            u128h terms = ((((u128h)1) << 64) - 1) / q2;
+            lc.lazy_terms = terms > (1u << 20) ? (1u << 20) : static_cast<uint32_t>(terms);
+        } else {
+            lc.lazy_terms = 1;
+        }
+    }
+    ctx->crt_bits = crt_bits;
+
+    // Garner table: garner_inv[i*L + j] = (q_j)^-1 mod q_i for j < i
+    // (mixed-radix CRT as the reference builds it, Runtime.cu:77-96)
+    ctx->garner_inv.assign(moduli_len * moduli_len, 0);
+    for (size_t i = 0; i < moduli_len; ++i)
+        for (size_t j = 0; j < i; ++j)
+            ctx->garner_inv[i * moduli_len + j] = h_invmod_prime(moduli[j] % moduli[i], moduli[i]);
+
+    int rc = 0;
+    e = hipMalloc(&ctx->d_limbs, sizeof(LimbConst) * moduli_len);
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->d_limbs, ctx->limbs.data(), sizeof(LimbConst) * moduli_len, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_garner, sizeof(uint64_t) * moduli_len * moduli_len);
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->d_garner, ctx->garner_inv.data(), sizeof(uint64_t) * moduli_len * moduli_len,
+                      hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = set_error(e, "context constant upload");
+    if (!rc) rc = wide ? upload_tables<uint64_t>(ctx, fwd, inv) : upload_tables<uint32_t>(ctx, fwd, inv);
+    if (!rc) {
+        e = hipEventCreate(&ctx->timer_start);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->timer_stop);
+        if (e != hipSuccess) rc = set_error(e, "hipEventCreate");
+    }
+    if (rc) {
+        std::string keep = g_last_error;
+        context_release(ctx);
+        g_last_error = keep;
+        return rc;
+    }
+    *out_ctx = ctx;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" void gpu_context_destroy(GpuContext *ctx) { context_release(ctx); }
+
+extern "C" int gpu_context_get_N(const GpuContext *ctx, int *out_N) {
+    if (!ctx || !out_N) return set_error("gpu_context_get_N: null argument");
+    *out_N = ctx->N;
+    return 0;
+}
+
+extern "C" int gpupoly_context_device(const GpuContext *ctx, int *out_device) {
+    if (!ctx || !out_device) return set_error("gpupoly_context_device: null argument");
+    *out_device = ctx->device;
+    return 0;
+}
+
+extern "C" int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes) {
+    if (!ctx || !out_bytes) return set_error("gpupoly_context_word_bytes: null argument");
+    *out_bytes = ctx->word_bytes;
+    return 0;
+}
+
+// ---- events ---------------------------------------------------------------------------
+extern "C" int gpu_event_set_wait(GpuEventSet *events) {
+    ABI_GUARD_BEGIN
+    if (!events) return 0;
+    HIP_TRY(hipSetDevice(events->device));
+    for (hipEvent_t ev : events->events) HIP_TRY(hipEventSynchronize(ev));
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" void gpu_event_set_destroy(GpuEventSet *events) {
+    if (!events) return;
+    (void)hipSetDevice(events->device);
+    for (hipEvent_t ev : events->events) {
+        (void)hipEventSynchronize(ev);
+        (void)hipEventDestroy(ev);
+    }
+    if (events->staging) (void)hipHostFree(events->staging);
+    if (events->dev_staging && events->ctx) ctx_free(events->ctx, events->dev_staging);
+    delete events;
+}
+
+// ---- device queries ---------------------------------------------------------------------
+extern "C" int gpu_device_count(int *out_count) {
+    ABI_GUARD_BEGIN
+    if (!out_count) return set_error("gpu_device_count: null out_count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        return set_error(e, "hipGetDeviceCount");
+    }
+    *out_count = n;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_device_mem_info(int device, size_t *out_free, size_t *out_total) {
+    ABI_GUARD_BEGIN
+    if (!out_free || !out_total) return set_error("gpu_device_mem_info: null output");
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = hipMemGetInfo(out_free, out_total);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return set_error(e, "hipMemGetInfo");
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_device_synchronize(void) {
+    ABI_GUARD_BEGIN
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    for (int d = 0; d < n; ++d) {
+        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    HIP_TRY(hipSetDevice(prev));
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_device_reset(void) {
+    ABI_GUARD_BEGIN
+    HIP_TRY(hipDeviceReset());
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" void *gpu_pinned_alloc(size_t bytes) {
+    if (bytes == 0) return nullptr;
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error(e, "hipHostMalloc");
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void gpu_pinned_free(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
+
+// ---- bench timer (extension) ----------------------------------------------------------------
+extern "C" int gpupoly_timer_start(GpuContext *ctx) {
+    ABI_GUARD_BEGIN
+    if (!ctx) return set_error("gpupoly_timer_start: null ctx");
+    if (ctx_activate(ctx)) return 1;
+    HIP_TRY(hipEventRecord(ctx->timer_start, ctx->stream));
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpupoly_timer_stop(GpuContext *ctx, float *out_ms) {
+    ABI_GUARD_BEGIN
+    if (!ctx || !out_ms) return set_error("gpupoly_timer_stop: null argument");
+    if (ctx_activate(ctx)) return 1;
+    HIP_TRY(hipEventRecord(ctx->timer_stop, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->timer_stop));
+    HIP_TRY(hipEventElapsedTime(out_ms, ctx->timer_start, ctx->timer_stop));
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpupoly_timer_mark(GpuContext *ctx, uint32_t slot) {
+    ABI_GUARD_BEGIN
+    if (!ctx) return set_error("gpupoly_timer_mark: null ctx");
+    if (slot >= 65536) return set_error("gpupoly_timer_mark: slot out of range");
+    if (ctx_activate(ctx)) return 1;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mutex);
+        if (ctx->marks.size() <= slot) ctx->marks.resize(slot + 1, nullptr);
+        if (!ctx->marks[slot]) HIP_TRY(hipEventCreate(&ctx->marks[slot]));
+    }
+    HIP_TRY(hipEventRecord(ctx->marks[slot], ctx->stream));
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpupoly_timer_elapsed(GpuContext *ctx, uint32_t slot_begin, uint32_t slot_end, float *out_ms) {
+    ABI_GUARD_BEGIN
+    if (!ctx || !out_ms) return set_error("gpupoly_timer_elapsed: null argument");
+    if (slot_begin >= ctx->marks.size() || slot_end >= ctx->marks.size() || !ctx->marks[slot_begin] ||
+        !ctx->marks[slot_end])
+        return set_error("gpupoly_timer_elapsed: slot was never marked");
+    if (ctx_activate(ctx)) return 1;
+    HIP_TRY(hipEventSynchronize(ctx->marks[slot_end]));
+    HIP_TRY(hipEventElapsedTime(out_ms, ctx->marks[slot_begin], ctx->marks[slot_end]));
+    return 0;
+    ABI_GUARD_END
+}

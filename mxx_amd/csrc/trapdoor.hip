@@ -1,0 +1,454 @@
+// trapdoor.hip — G-lattice sampling and the p1 perturbation sampler of the
+// trapdoor-preimage path.  Replaces cuda/src/matrix/MatrixTrapdoor.cu behind
+// cuda/include/matrix/MatrixTrapdoor.cuh:66-101.
+//
+// G-sampling (Genise-Micciancio "GaussSampGqArbBase", the algorithm OpenFHE's
+// DCRTGaussSampGqArbBase implements; reference kernel MatrixTrapdoor.cu:701-833):
+// for tower t and coefficient value v in [0,q_t), sample z in Z^dpt from the coset
+// of Lambda(g_t) with sum_d b^d z_d = v (mod q_t), width c.  One thread per
+// (entry, tower, coefficient) samples the dpt digits and writes their residues
+// into all output limbs directly (no int64 staging buffer, no scatter launch).
+//
+// p1 perturbation (reference MatrixTrapdoor.cu:95-360):
+// per coefficient index the 2d x 2d covariance [[s^2 I - c^2 A, -c^2 B],
+// [-c^2 B^T, s^2 I - c^2 D]] (A,B,D centred limb-0 coefficients) is factored once
+// into conditional standard deviations + update columns (the cache); sampling then
+// walks t = m-1..0 with Karney integers and mean updates.
+#include "common.h"
+#include "modarith.h"
+#include "rng.h"
+
+#include <algorithm>
+
+static constexpr uint64_t kTagGadget = 0x6761646765746731ull;
+static constexpr uint64_t kTagP1 = 0x7065727475726231ull;
+static constexpr int kGaussMaxDigits = 64;
+
+// ---- G-lattice sampler ------------------------------------------------------------------------
+template <typename W, int MAXD>
+__global__ void gauss_samp_gq_kernel(W *__restrict__ out, const W *__restrict__ src,
+                                     const LimbConst *__restrict__ limbs, size_t src_polys, uint32_t src_cols,
+                                     uint32_t L, uint32_t N, uint32_t dpt, uint32_t base_bits, double c, size_t k,
+                                     GpuRngSeed seed) {
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t total = src_polys * L * N;
+    if (idx >= total) return;
+    const uint32_t i = static_cast<uint32_t>(idx % N);
+    const size_t pt = idx / N;
+    const uint32_t t = static_cast<uint32_t>(pt % L);
+    const size_t p = pt / L;
+    const uint64_t qt = limbs[t].q;
+    uint64_t value = static_cast<uint64_t>(src[(p * L + t) * N + i]) % qt;
+
+    const uint64_t base = 1ull << base_bits;
+    const double base_f = static_cast<double>(base);
+    const double sigma = c / (base_f + 1.0);
+    const double kf = static_cast<double>(dpt);
+
+    int64_t m_digits[MAXD], v_digits[MAXD], z[MAXD];
+    double a[MAXD], zf[MAXD], cvec[MAXD];
+    {
+        uint64_t mq = qt, vv = value;
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d) {
+            if (d < (int)dpt) {
+                m_digits[d] = static_cast<int64_t>(mq % base);
+                mq /= base;
+                v_digits[d] = static_cast<int64_t>(vv % base);
+                vv /= base;
+            } else {
+                m_digits[d] = 0;
+                v_digits[d] = 0;
+            }
+        }
+    }
+    ChaChaRng rng;
+    rng_init(rng, seed, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1, static_cast<uint64_t>(i) + 1,
+             kTagGadget);
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) zf[d] = d < (int)dpt ? sigma * rng_standard_normal(rng) : 0.0;
+
+    // perturbation p = L-factor applied to zf; l_d, h_d are the Cholesky entries of the
+    // basis Gram matrix (Genise-Micciancio, alg. 3), folded into the running sums here
+    {
+        double prev_c = 0.0;
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d) {
+            if (d < (int)dpt) {
+                cvec[d] = (prev_c + static_cast<double>(m_digits[d])) / base_f;
+                prev_c = cvec[d];
+            } else {
+                cvec[d] = 0.0;
+            }
+        }
+        double prev_a = 0.0;
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d) {
+            if (d < (int)dpt) {
+                const double ld = d == 0 ? sqrt(base_f * (1.0 + 1.0 / kf) + 1.0)
+                                         : sqrt(base_f * (1.0 + 1.0 / (kf - static_cast<double>(d))));
+                double pd;
+                if (d + 1 < (int)dpt) {
+                    const double hn = sqrt(base_f * (1.0 - 1.0 / (kf - static_cast<double>(d))));
+                    pd = ld * zf[d] + hn * zf[d + 1 < MAXD ? d + 1 : d];
+                } else {
+                    const double hd = d == 0 ? 0.0 : sqrt(base_f * (1.0 - 1.0 / (kf - static_cast<double>(d - 1))));
+                    pd = hd * zf[d];
+                }
+                a[d] = (prev_a + static_cast<double>(v_digits[d]) - pd) / base_f;
+                prev_a = a[d];
+            } else {
+                a[d] = 0.0;
+            }
+        }
+    }
+    const int last = static_cast<int>(dpt) - 1;
+    double a_last = 0.0, c_last = 1.0;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+        if (d == last) {
+            a_last = a[d];
+            c_last = cvec[d];
+        }
+    const int64_t z_last = sample_integer_karney(rng, -a_last / c_last, sigma / c_last);
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) a[d] += static_cast<double>(z_last) * cvec[d];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+        if (d < last) z[d] = sample_integer_karney(rng, -a[d], sigma);
+        else z[d] = z_last;
+    }
+
+    const size_t r = p / src_cols, col = p - r * src_cols;
+    int64_t z_prev = 0;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+        if (d < (int)dpt) {
+            int64_t digit;
+            if (dpt == 1) digit = static_cast<int64_t>(base) * z[0] + m_digits[0] * z[0] + v_digits[0];
+            else if (d == 0) digit = static_cast<int64_t>(base) * z[0] + m_digits[0] * z_last + v_digits[0];
+            else if (d < last) digit = static_cast<int64_t>(base) * z[d] - z_prev + m_digits[d] * z_last + v_digits[d];
+            else digit = m_digits[d] * z_last - z_prev + v_digits[d];
+            z_prev = z[d];
+            const size_t orow = r * k + static_cast<size_t>(t) * dpt + d;
+            const size_t opoly = orow * src_cols + col;
+            for (uint32_t l = 0; l < L; ++l)
+                out[(opoly * L + l) * N + i] = signed_to_residue<W>(digit, static_cast<W>(limbs[l].q));
+        }
+    }
+}
+
+template <typename W>
+static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys, uint32_t src_cols, uint32_t L,
+                             uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
+    const size_t total = polys * L * static_cast<size_t>(ctx->N);
+    const unsigned blocks = static_cast<unsigned>((total + 127) / 128);
+    const uint32_t N = static_cast<uint32_t>(ctx->N);
+#define LAUNCH_GS(MAXD)                                                                                        \
+    hipLaunchKernelGGL((gauss_samp_gq_kernel<W, MAXD>), dim3(blocks), dim3(128), 0, ctx->stream, out, src,      \
+                       ctx->d_limbs, polys, src_cols, L, N, dpt, base_bits, c, k, seed)
+    if (dpt <= 2) LAUNCH_GS(2);
+    else if (dpt <= 4) LAUNCH_GS(4);
+    else if (dpt <= 8) LAUNCH_GS(8);
+    else if (dpt <= 20) LAUNCH_GS(20);
+    else LAUNCH_GS(64);
+#undef LAUNCH_GS
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpu_matrix_gauss_samp_gq_arb_base(GpuMatrix *src, uint32_t base_bits, double c, double dgg_stddev,
+                                                 GpuRngSeed seed, GpuMatrix *out) {
+    ABI_GUARD_BEGIN
+    (void)dgg_stddev;  // unused by the reference too (MatrixTrapdoor.cu:1680)
+    if (!src || !out) return set_error("invalid gpu_matrix_gauss_samp_gq_arb_base arguments");
+    if (base_bits == 0 || base_bits >= 63) return set_error("invalid base_bits in gpu_matrix_gauss_samp_gq_arb_base");
+    if (!(c > 0.0)) return set_error("c must be positive in gpu_matrix_gauss_samp_gq_arb_base");
+    if (src->ctx != out->ctx || src->level != out->level)
+        return set_error("context mismatch in gpu_matrix_gauss_samp_gq_arb_base");
+    GpuContext *ctx = src->ctx;
+    const int requested = out->format;
+    const size_t L = matrix_limbs(src);
+    const uint32_t dpt = (ctx->crt_bits + base_bits - 1) / base_bits;
+    if (dpt == 0 || dpt > kGaussMaxDigits)
+        return set_error("invalid digits_per_tower in gpu_matrix_gauss_samp_gq_arb_base");
+    const size_t k = static_cast<size_t>(dpt) * L;
+    if (out->rows != src->rows * k || out->cols != src->cols)
+        return set_error("output size mismatch in gpu_matrix_gauss_samp_gq_arb_base");
+    const size_t polys = matrix_polys(src);
+    if (polys == 0) {
+        out->format = GPU_POLY_FORMAT_EVAL;
+        return 0;
+    }
+    if (ctx_activate(ctx)) return 1;
+    if (src->format == GPU_POLY_FORMAT_EVAL) {  // the source is consumed: convert in place
+        int rc = gpu_matrix_intt_all(src);
+        if (rc) return rc;
+    }
+    int rc = ctx->wide ? launch_gauss_samp<uint64_t>(ctx, static_cast<uint64_t *>(out->data),
+                                                     static_cast<const uint64_t *>(src->data), polys,
+                                                     (uint32_t)src->cols, (uint32_t)L, dpt, base_bits, c, k, seed)
+                       : launch_gauss_samp<uint32_t>(ctx, static_cast<uint32_t *>(out->data),
+                                                     static_cast<const uint32_t *>(src->data), polys,
+                                                     (uint32_t)src->cols, (uint32_t)L, dpt, base_bits, c, k, seed);
+    if (rc) return rc;
+    out->format = GPU_POLY_FORMAT_COEFF;
+    if (requested == GPU_POLY_FORMAT_EVAL) {
+        rc = launch_ntt(ctx, out->data, matrix_polys(out) * L, static_cast<int>(L), false);
+        if (rc) return rc;
+        out->format = GPU_POLY_FORMAT_EVAL;
+    }
+    return 0;
+    ABI_GUARD_END
+}
+
+// ---- p1 perturbation sampler -------------------------------------------------------------------
+template <typename W>
+__global__ void p1_covariance_kernel(const W *__restrict__ a_mat, const W *__restrict__ b_mat,
+                                     const W *__restrict__ d_mat, uint32_t d, uint32_t L, uint32_t N, uint64_t q0,
+                                     double sigma, double s, double dgg_stddev, double *__restrict__ cov_ws,
+                                     double *__restrict__ sqrt_var_out, double *__restrict__ update_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t m = 2 * d;
+    double *cov = cov_ws + static_cast<size_t>(i) * m * m;
+    double *sqrt_var = sqrt_var_out + static_cast<size_t>(i) * m;
+    double *upd = update_out + static_cast<size_t>(i) * m * m;
+    const double sigma2 = sigma * sigma, s2 = s * s, fallback = dgg_stddev * dgg_stddev, eps = 1e-9;
+    // limb 0 of entry (r,c): word offset ((r*d+c)*L + 0)*N + i
+    for (uint32_t r = 0; r < d; ++r)
+        for (uint32_t c = 0; c < d; ++c) {
+            const size_t rc = (static_cast<size_t>(r) * d + c) * L * N + i;
+            const size_t cr = (static_cast<size_t>(c) * d + r) * L * N + i;
+            const double a_rc = static_cast<double>(centered_residue(a_mat[rc], q0));
+            const double d_rc = static_cast<double>(centered_residue(d_mat[rc], q0));
+            const double b_rc = static_cast<double>(centered_residue(b_mat[rc], q0));
+            const double b_cr = static_cast<double>(centered_residue(b_mat[cr], q0));
+            cov[r * m + c] = -sigma2 * a_rc + (r == c ? s2 : 0.0);
+            cov[(r + d) * m + (c + d)] = -sigma2 * d_rc + (r == c ? s2 : 0.0);
+            cov[r * m + (c + d)] = -sigma2 * b_rc;
+            cov[(r + d) * m + c] = -sigma2 * b_cr;
+        }
+    for (int t = static_cast<int>(m) - 1; t >= 0; --t) {
+        double var = cov[t * m + t];
+        if (!(var > eps)) var = fallback;
+        sqrt_var[t] = sqrt(var);
+        for (int r = 0; r < t; ++r) upd[t * m + r] = cov[r * m + t] / var;
+        if (t == 0) break;
+        for (int r = 0; r < t; ++r) {
+            const double cr = upd[t * m + r];
+            for (int c = 0; c <= r; ++c) {
+                const double colc = upd[t * m + c] * var;
+                const double v = cov[r * m + c] - cr * colc;
+                cov[r * m + c] = v;
+                cov[c * m + r] = v;
+            }
+        }
+    }
+}
+
+// MAXM > 0: mean/sample vectors in registers; MAXM == 0: per-thread slices of a global workspace
+template <typename W, int MAXM>
+__global__ void p1_sample_kernel(W *__restrict__ out, const W *__restrict__ tp2,
+                                 const LimbConst *__restrict__ limbs, const double *__restrict__ sqrt_var_base,
+                                 const double *__restrict__ update_base, uint32_t m, uint32_t cols, uint32_t L,
+                                 uint32_t N, uint64_t q0, double c_scale, GpuRngSeed seed,
+                                 double *__restrict__ mean_ws) {
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= static_cast<size_t>(cols) * N) return;
+    const uint32_t col = static_cast<uint32_t>(idx / N);
+    const uint32_t i = static_cast<uint32_t>(idx - static_cast<size_t>(col) * N);
+    const double *sqrt_var = sqrt_var_base + static_cast<size_t>(i) * m;
+    const double *upd = update_base + static_cast<size_t>(i) * m * m;
+    ChaChaRng rng;
+    rng_init(rng, seed, static_cast<uint64_t>(col) + 1, static_cast<uint64_t>(i) + 1, 0, kTagP1);
+
+    if constexpr (MAXM > 0) {
+        double mean[MAXM];
+#pragma unroll
+        for (int r = 0; r < MAXM; ++r)
+            mean[r] = r < (int)m ? c_scale * static_cast<double>(centered_residue(
+                                                 tp2[((static_cast<size_t>(r) * cols + col) * L) * N + i], q0))
+                                 : 0.0;
+#pragma unroll
+        for (int t = MAXM - 1; t >= 0; --t) {
+            if (t >= (int)m) continue;
+            const double mu = mean[t];
+            const int64_t z = sample_integer_karney(rng, mu, sqrt_var[t]);
+            for (uint32_t l = 0; l < L; ++l)
+                out[((static_cast<size_t>(t) * cols + col) * L + l) * N + i] =
+                    signed_to_residue<W>(z, static_cast<W>(limbs[l].q));
+            const double delta = static_cast<double>(z) - mu;
+#pragma unroll
+            for (int r = 0; r < MAXM; ++r)
+                if (r < t) mean[r] += upd[t * m + r] * delta;
+        }
+    } else {
+        double *mean = mean_ws + idx * m;
+        for (uint32_t r = 0; r < m; ++r)
+            mean[r] = c_scale * static_cast<double>(centered_residue(
+                                    tp2[((static_cast<size_t>(r) * cols + col) * L) * N + i], q0));
+        for (int t = static_cast<int>(m) - 1; t >= 0; --t) {
+            const double mu = mean[t];
+            const int64_t z = sample_integer_karney(rng, mu, sqrt_var[t]);
+            for (uint32_t l = 0; l < L; ++l)
+                out[((static_cast<size_t>(t) * cols + col) * L + l) * N + i] =
+                    signed_to_residue<W>(z, static_cast<W>(limbs[l].q));
+            const double delta = static_cast<double>(z) - mu;
+            for (int r = 0; r < t; ++r) mean[r] += upd[t * m + r] * delta;
+        }
+    }
+}
+
+static int check_p1_inputs(const GpuMatrix *a, const GpuMatrix *b, const GpuMatrix *d, double sigma, double s,
+                           double dgg_stddev, const char *who) {
+    if (!a || !b || !d) return set_error(std::string("invalid ") + who + " arguments");
+    if (!(sigma > 0.0) || !(s > sigma)) return set_error(std::string("invalid sigma/s in ") + who);
+    if (!(dgg_stddev > 0.0)) return set_error(std::string("dgg_stddev must be positive in ") + who);
+    if (a->ctx != b->ctx || a->ctx != d->ctx) return set_error(std::string("context mismatch in ") + who);
+    if (a->level != b->level || a->level != d->level) return set_error(std::string("level mismatch in ") + who);
+    const size_t dr = a->rows;
+    if (a->cols != dr || b->rows != dr || b->cols != dr || d->rows != dr || d->cols != dr)
+        return set_error(std::string("A/B/D must be dxd in ") + who);
+    if (a->format != GPU_POLY_FORMAT_COEFF || b->format != GPU_POLY_FORMAT_COEFF || d->format != GPU_POLY_FORMAT_COEFF)
+        return set_error(std::string("A/B/D must be in Coeff format in ") + who);
+    return 0;
+}
+
+extern "C" int gpu_matrix_create_p1_covariance_cache(const GpuMatrix *a_mat, const GpuMatrix *b_mat,
+                                                     const GpuMatrix *d_mat, double sigma, double s, double dgg_stddev,
+                                                     GpuP1CovarianceCache **out_cache) {
+    ABI_GUARD_BEGIN
+    if (!out_cache) return set_error("gpu_matrix_create_p1_covariance_cache: null out_cache");
+    *out_cache = nullptr;
+    if (check_p1_inputs(a_mat, b_mat, d_mat, sigma, s, dgg_stddev, "gpu_matrix_create_p1_covariance_cache")) return 1;
+    GpuContext *ctx = a_mat->ctx;
+    const size_t d = a_mat->rows, m = 2 * d, n = static_cast<size_t>(ctx->N);
+    GpuP1CovarianceCache *cache = new GpuP1CovarianceCache();
+    cache->ctx = ctx;
+    cache->level = a_mat->level;
+    cache->d = d;
+    cache->m = m;
+    cache->n = n;
+    cache->sigma = sigma;
+    cache->s = s;
+    cache->dgg_stddev = dgg_stddev;
+    if (d == 0) {
+        *out_cache = cache;
+        return 0;
+    }
+    if (ctx_activate(ctx)) {
+        delete cache;
+        return 1;
+    }
+    void *cov_ws = nullptr, *sv = nullptr, *uc = nullptr;
+    if (ctx_alloc(ctx, n * m * m * sizeof(double), &cov_ws) || ctx_alloc(ctx, n * m * sizeof(double), &sv) ||
+        ctx_alloc(ctx, n * m * m * sizeof(double), &uc)) {
+        ctx_free(ctx, cov_ws);
+        ctx_free(ctx, sv);
+        ctx_free(ctx, uc);
+        delete cache;
+        return 1;
+    }
+    cache->sqrt_var = static_cast<double *>(sv);
+    cache->update_coeff = static_cast<double *>(uc);
+    HIP_TRY(hipMemsetAsync(uc, 0, n * m * m * sizeof(double), ctx->stream));
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(a_mat));
+    const unsigned blocks = static_cast<unsigned>((n + 127) / 128);
+    if (ctx->wide)
+        hipLaunchKernelGGL(p1_covariance_kernel<uint64_t>, dim3(blocks), dim3(128), 0, ctx->stream,
+                           static_cast<const uint64_t *>(a_mat->data), static_cast<const uint64_t *>(b_mat->data),
+                           static_cast<const uint64_t *>(d_mat->data), (uint32_t)d, L, (uint32_t)n, ctx->moduli[0],
+                           sigma, s, dgg_stddev, static_cast<double *>(cov_ws), cache->sqrt_var, cache->update_coeff);
+    else
+        hipLaunchKernelGGL(p1_covariance_kernel<uint32_t>, dim3(blocks), dim3(128), 0, ctx->stream,
+                           static_cast<const uint32_t *>(a_mat->data), static_cast<const uint32_t *>(b_mat->data),
+                           static_cast<const uint32_t *>(d_mat->data), (uint32_t)d, L, (uint32_t)n, ctx->moduli[0],
+                           sigma, s, dgg_stddev, static_cast<double *>(cov_ws), cache->sqrt_var, cache->update_coeff);
+    hipError_t e = hipGetLastError();
+    ctx_free(ctx, cov_ws);
+    if (e != hipSuccess) {
+        gpu_matrix_destroy_p1_covariance_cache(cache);
+        return set_error(e, "p1_covariance_kernel");
+    }
+    *out_cache = cache;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" void gpu_matrix_destroy_p1_covariance_cache(GpuP1CovarianceCache *cache) {
+    if (!cache) return;
+    if (cache->ctx) {
+        (void)hipSetDevice(cache->ctx->device);
+        ctx_free(cache->ctx, cache->sqrt_var);
+        ctx_free(cache->ctx, cache->update_coeff);
+    }
+    delete cache;
+}
+
+extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cache, const GpuMatrix *tp2,
+                                                GpuRngSeed seed, GpuMatrix *out) {
+    ABI_GUARD_BEGIN
+    if (!cache || !tp2 || !out) return set_error("invalid gpu_matrix_sample_p1_full_cached arguments");
+    GpuContext *ctx = cache->ctx;
+    if (tp2->ctx != ctx || out->ctx != ctx) return set_error("context mismatch in gpu_matrix_sample_p1_full_cached");
+    if (tp2->level != cache->level || out->level != cache->level)
+        return set_error("level mismatch in gpu_matrix_sample_p1_full_cached");
+    const size_t m = cache->m, cols = tp2->cols;
+    if (tp2->rows != m || out->rows != m || out->cols != cols)
+        return set_error("tp2/out shape mismatch in gpu_matrix_sample_p1_full_cached");
+    if (cols == 0 || m == 0) {
+        out->format = GPU_POLY_FORMAT_EVAL;
+        return 0;
+    }
+    if (tp2->format != GPU_POLY_FORMAT_COEFF)
+        return set_error("tp2 must be in Coeff format in gpu_matrix_sample_p1_full_cached");
+    const double denom = cache->s * cache->s - cache->sigma * cache->sigma;
+    if (!(denom > 0.0)) return set_error("invalid cached Gaussian denominator");
+    const double c_scale = -(cache->sigma * cache->sigma) / denom;
+    if (ctx_activate(ctx)) return 1;
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(out)), N = static_cast<uint32_t>(ctx->N);
+    const size_t total = cols * static_cast<size_t>(N);
+    const unsigned blocks = static_cast<unsigned>((total + 127) / 128);
+    void *mean_ws = nullptr;
+    if (m > 8 && ctx_alloc(ctx, total * m * sizeof(double), &mean_ws)) return 1;
+#define LAUNCH_P1(WT, MAXM)                                                                                       \
+    hipLaunchKernelGGL((p1_sample_kernel<WT, MAXM>), dim3(blocks), dim3(128), 0, ctx->stream,                      \
+                       static_cast<WT *>(out->data), static_cast<const WT *>(tp2->data), ctx->d_limbs,             \
+                       cache->sqrt_var, cache->update_coeff, (uint32_t)m, (uint32_t)cols, L, N, ctx->moduli[0],    \
+                       c_scale, seed, static_cast<double *>(mean_ws))
+    if (ctx->wide) {
+        if (m <= 2) LAUNCH_P1(uint64_t, 2);
+        else if (m <= 4) LAUNCH_P1(uint64_t, 4);
+        else if (m <= 8) LAUNCH_P1(uint64_t, 8);
+        else LAUNCH_P1(uint64_t, 0);
+    } else {
+        if (m <= 2) LAUNCH_P1(uint32_t, 2);
+        else if (m <= 4) LAUNCH_P1(uint32_t, 4);
+        else if (m <= 8) LAUNCH_P1(uint32_t, 8);
+        else LAUNCH_P1(uint32_t, 0);
+    }
+#undef LAUNCH_P1
+    hipError_t e = hipGetLastError();
+    if (mean_ws) ctx_free(ctx, mean_ws);
+    if (e != hipSuccess) return set_error(e, "p1_sample_kernel");
+    // always finishes in EVAL
+    int rc = launch_ntt(ctx, out->data, matrix_polys(out) * L, static_cast<int>(L), false);
+    if (rc) return rc;
+    out->format = GPU_POLY_FORMAT_EVAL;
+    return 0;
+    ABI_GUARD_END
+}
+
+extern "C" int gpu_matrix_sample_p1_full(const GpuMatrix *a_mat, const GpuMatrix *b_mat, const GpuMatrix *d_mat,
+                                         const GpuMatrix *tp2, double sigma, double s, double dgg_stddev,
+                                         GpuRngSeed seed, GpuMatrix *out) {
+    ABI_GUARD_BEGIN
+    GpuP1CovarianceCache *cache = nullptr;
+    int rc = gpu_matrix_create_p1_covariance_cache(a_mat, b_mat, d_mat, sigma, s, dgg_stddev, &cache);
+    if (rc) return rc;
+    rc = gpu_matrix_sample_p1_full_cached(cache, tp2, seed, out);
+    gpu_matrix_destroy_p1_covariance_cache(cache);
+    return rc;
+    ABI_GUARD_END
+}

@@ -1,0 +1,571 @@
+"""`GpuDCRTPolyMatrix` — host-side mirror of the reference's GPU matrix wrapper.
+
+Same names, argument meaning and error behaviour as
+`src/matrix/gpu_dcrt_poly.rs:221-1678,1716-1895` (the `PolyMatrix` trait is
+`src/matrix/mod.rs:45-379`); every method is a thin sequence of C-ABI calls into
+libgpupoly (include/gpupoly.h).  Host data crosses the boundary as numpy uint64
+arrays in the wire layout (rows, cols, level+1, n) — the `[poly][limb][n]` u64
+layout of `load/store_rns_bytes` (gpu_dcrt_poly.rs:576-663).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import GPU_POLY_FORMAT_COEFF, GPU_POLY_FORMAT_EVAL, GpuRngSeed, check_status
+from .params import GpuDCRTPolyParams
+
+
+def mul_decompose_column_chunk_width() -> int:
+    """`MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH`, default 1 (src/env.rs of the reference)."""
+    try:
+        return max(1, int(os.environ.get("MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH", "1")))
+    except ValueError:
+        return 1
+
+
+class GpuP1CovarianceCache:
+    def __init__(self, raw):
+        self.raw = raw
+        self._finalizer = weakref.finalize(self, _ffi.lib().gpu_matrix_destroy_p1_covariance_cache, raw)
+
+
+class GpuDCRTPolyMatrix:
+    __slots__ = ("params", "nrow", "ncol", "level", "is_ntt", "raw", "_finalizer", "__weakref__")
+
+    # ------------------------------------------------------------------ construction
+    def __init__(self, params: GpuDCRTPolyParams, nrow: int, ncol: int, level: int, is_ntt: bool):
+        """`new_empty_with_state` (gpu_dcrt_poly.rs:222-256): contents undefined."""
+        if not (0 <= level < params.crt_depth()):
+            raise AssertionError("invalid level for matrix create")
+        raw = C.c_void_p()
+        fmt = GPU_POLY_FORMAT_EVAL if is_ntt else GPU_POLY_FORMAT_COEFF
+        st = _ffi.lib().gpu_matrix_create(params.ctx_raw(), level, nrow, ncol, fmt, C.byref(raw))
+        check_status(st, f"gpu_matrix_create(nrow={nrow}, ncol={ncol}, level={level}, format={fmt})")
+        self.params = params
+        self.nrow = nrow
+        self.ncol = ncol
+        self.level = level
+        self.is_ntt = is_ntt
+        self.raw = raw
+        self._finalizer = weakref.finalize(self, _ffi.lib().gpu_matrix_destroy, raw)
+
+    @classmethod
+    def new_empty(cls, params, nrow, ncol) -> "GpuDCRTPolyMatrix":
+        return cls(params, nrow, ncol, params.crt_depth() - 1, True)
+
+    @classmethod
+    def zero(cls, params, nrow, ncol) -> "GpuDCRTPolyMatrix":
+        return cls._new_zero_with_state(params, nrow, ncol, params.crt_depth() - 1, True)
+
+    @classmethod
+    def _new_zero_with_state(cls, params, nrow, ncol, level, is_ntt) -> "GpuDCRTPolyMatrix":
+        out = cls(params, nrow, ncol, level, is_ntt)
+        if nrow == 0 or ncol == 0:
+            return out
+        n = params.ring_dimension()
+        out.load_rns(np.zeros((nrow, ncol, level + 1, n), dtype=np.uint64), is_ntt)
+        return out
+
+    @classmethod
+    def from_rns(cls, params, data: np.ndarray, eval_format: bool) -> "GpuDCRTPolyMatrix":
+        """Upload wire-layout residues (rows, cols, L, n)."""
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        rows, cols, L, n = data.shape
+        if n != params.ring_dimension():
+            raise ValueError("ring dimension mismatch")
+        out = cls(params, rows, cols, L - 1, eval_format)
+        out.load_rns(data, eval_format)
+        return out
+
+    @classmethod
+    def from_cpu_matrix(cls, params, coeff_residues: np.ndarray) -> "GpuDCRTPolyMatrix":
+        """`from_cpu_matrix` (gpu_dcrt_poly.rs:769-817): CPU matrices travel as EVAL residues."""
+        return cls.from_rns(params, coeff_residues, True)
+
+    @classmethod
+    def identity(cls, params, size, scalar=None) -> "GpuDCRTPolyMatrix":
+        n, L = params.ring_dimension(), params.crt_depth()
+        host = np.zeros((size, size, L, n), dtype=np.uint64)
+        if size:
+            if scalar is None:
+                diag = np.ones((L, n), dtype=np.uint64)  # EVAL form of the constant 1
+            else:
+                sm = scalar.inner if hasattr(scalar, "inner") else scalar
+                diag = sm.ensure_eval().to_rns()[0, 0]
+            for i in range(size):
+                host[i, i] = diag
+        return cls.from_rns(params, host, True)
+
+    @classmethod
+    def gadget_matrix(cls, params, size) -> "GpuDCRTPolyMatrix":
+        if size == 0:
+            return cls.zero(params, 0, 0)
+        out = cls.new_empty(params, size, size * params.modulus_digits())
+        check_status(_ffi.lib().gpu_matrix_fill_gadget(out.raw, params.base_bits()), "gpu_matrix_fill_gadget")
+        out.is_ntt = True
+        return out
+
+    @classmethod
+    def small_gadget_matrix(cls, params, size) -> "GpuDCRTPolyMatrix":
+        if size == 0:
+            return cls.zero(params, 0, 0)
+        k = -(-params.crt_bits() // params.base_bits())
+        out = cls.new_empty(params, size, size * k)
+        check_status(_ffi.lib().gpu_matrix_fill_small_gadget(out.raw, params.base_bits()), "gpu_matrix_fill_small_gadget")
+        out.is_ntt = True
+        return out
+
+    # ------------------------------------------------------------------ host transfer
+    def _bytes_per_poly(self) -> int:
+        return (self.level + 1) * self.params.ring_dimension() * 8
+
+    def load_rns(self, data: np.ndarray, eval_format: bool) -> None:
+        """`load_rns_bytes` (gpu_dcrt_poly.rs:629-663)."""
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        if data.size == 0:
+            self.is_ntt = eval_format
+            return
+        if data.size != self.nrow * self.ncol * (self.level + 1) * self.params.ring_dimension():
+            raise ValueError("load_rns: size mismatch")
+        events = C.c_void_p()
+        fmt = GPU_POLY_FORMAT_EVAL if eval_format else GPU_POLY_FORMAT_COEFF
+        st = _ffi.lib().gpu_matrix_load_rns_batch(self.raw, data.ctypes.data, self._bytes_per_poly(), fmt, C.byref(events))
+        check_status(st, "gpu_matrix_load_rns_batch")
+        _ffi.wait_and_destroy_events(events)
+        self.is_ntt = eval_format
+
+    def to_rns(self) -> np.ndarray:
+        """`store_rns_bytes` in the current format (gpu_dcrt_poly.rs:576-596)."""
+        n = self.params.ring_dimension()
+        out = np.zeros((self.nrow, self.ncol, self.level + 1, n), dtype=np.uint64)
+        if out.size == 0:
+            return out
+        events = C.c_void_p()
+        fmt = GPU_POLY_FORMAT_EVAL if self.is_ntt else GPU_POLY_FORMAT_COEFF
+        st = _ffi.lib().gpu_matrix_store_rns_batch(self.raw, out.ctypes.data, self._bytes_per_poly(), fmt, C.byref(events))
+        check_status(st, "gpu_matrix_store_rns_batch")
+        _ffi.wait_and_destroy_events(events)
+        return out
+
+    def to_coeff_rns(self) -> np.ndarray:
+        return self.ensure_coeff().to_rns()
+
+    def to_eval_rns(self) -> np.ndarray:
+        return self.ensure_eval().to_rns()
+
+    def store_const_coeff_words(self) -> np.ndarray:
+        """`store_const_coeff_words` (gpu_dcrt_poly.rs:598-627); COEFF format required."""
+        L = self.level + 1
+        out = np.zeros((self.nrow, self.ncol, L), dtype=np.uint64)
+        if out.size == 0:
+            return out
+        events = C.c_void_p()
+        st = _ffi.lib().gpu_matrix_store_const_coeff_batch(self.raw, out.ctypes.data, L, C.byref(events))
+        check_status(st, "gpu_matrix_store_const_coeff_batch")
+        _ffi.wait_and_destroy_events(events)
+        return out
+
+    def coeffs(self) -> list:
+        """CRT-reconstructed coefficients as python ints, [row][col][i] (gpu.rs:959-994)."""
+        res = self.to_coeff_rns()
+        moduli = self.params.moduli()[: self.level + 1]
+        Q = 1
+        for q in moduli:
+            Q *= q
+        weights = []
+        for q in moduli:
+            Qi = Q // q
+            weights.append(Qi * pow(Qi, -1, q))
+        out = []
+        for r in range(self.nrow):
+            row = []
+            for c in range(self.ncol):
+                vals = [0] * res.shape[-1]
+                for l, w in enumerate(weights):
+                    limb = res[r, c, l]
+                    for i in range(len(vals)):
+                        vals[i] += int(limb[i]) * w
+                row.append([v % Q for v in vals])
+            out.append(row)
+        return out
+
+    # ------------------------------------------------------------------ domain
+    def ntt_all_in_place(self) -> None:
+        if self.nrow == 0 or self.ncol == 0 or self.is_ntt:
+            self.is_ntt = True
+            return
+        check_status(_ffi.lib().gpu_matrix_ntt_all(self.raw), "gpu_matrix_ntt_all")
+        self.is_ntt = True
+
+    def intt_all_in_place(self) -> None:
+        if self.nrow == 0 or self.ncol == 0 or not self.is_ntt:
+            return
+        check_status(_ffi.lib().gpu_matrix_intt_all(self.raw), "gpu_matrix_intt_all")
+        self.is_ntt = False
+
+    def into_coeff_domain(self) -> "GpuDCRTPolyMatrix":
+        self.intt_all_in_place()
+        return self
+
+    def ensure_coeff(self) -> "GpuDCRTPolyMatrix":
+        if not self.is_ntt:
+            return self
+        return self.clone().into_coeff_domain()
+
+    def ensure_eval(self) -> "GpuDCRTPolyMatrix":
+        if self.is_ntt:
+            return self
+        out = self.clone()
+        out.ntt_all_in_place()
+        return out
+
+    # ------------------------------------------------------------------ structure
+    def clone(self) -> "GpuDCRTPolyMatrix":
+        out = GpuDCRTPolyMatrix(self.params, self.nrow, self.ncol, self.level, self.is_ntt)
+        if self.nrow and self.ncol:
+            check_status(_ffi.lib().gpu_matrix_copy(out.raw, self.raw), "gpu_matrix_copy")
+        return out
+
+    def size(self):
+        return self.nrow, self.ncol
+
+    def row_size(self) -> int:
+        return self.nrow
+
+    def col_size(self) -> int:
+        return self.ncol
+
+    def copy_block_from(self, src, dst_row, dst_col, src_row, src_col, rows, cols) -> None:
+        if rows == 0 or cols == 0:
+            return
+        st = _ffi.lib().gpu_matrix_copy_block(self.raw, src.raw, dst_row, dst_col, src_row, src_col, rows, cols)
+        check_status(st, "gpu_matrix_copy_block")
+
+    def add_block_from(self, src, dst_row, dst_col, src_row, src_col, rows, cols) -> None:
+        assert self.params == src.params and self.level == src.level and self.is_ntt == src.is_ntt
+        if rows == 0 or cols == 0:
+            return
+        st = _ffi.lib().gpu_matrix_add_block(self.raw, src.raw, dst_row, dst_col, src_row, src_col, rows, cols)
+        check_status(st, "gpu_matrix_add_block")
+        self.is_ntt = src.is_ntt
+
+    def slice(self, row_start, row_end, col_start, col_end) -> "GpuDCRTPolyMatrix":
+        nrow, ncol = row_end - row_start, col_end - col_start
+        out = GpuDCRTPolyMatrix(self.params, nrow, ncol, self.level, self.is_ntt)
+        out.copy_block_from(self, 0, 0, row_start, col_start, nrow, ncol)
+        return out
+
+    def slice_rows(self, start, end):
+        return self.slice(start, end, 0, self.ncol)
+
+    def slice_columns(self, start, end):
+        return self.slice(0, self.nrow, start, end)
+
+    def entry(self, i, j):
+        from .poly import GpuDCRTPoly
+
+        return GpuDCRTPoly(self.slice(i, i + 1, j, j + 1))
+
+    def set_entry(self, i, j, elem) -> None:
+        src = elem.inner if hasattr(elem, "inner") else elem
+        # convert domains first so the whole-matrix retag of copy_block stays harmless
+        # (gpu_dcrt_poly.rs:1122-1132)
+        src = src.ensure_eval() if self.is_ntt else src.ensure_coeff()
+        self.copy_block_from(src, i, j, 0, 0, 1, 1)
+
+    def get_row(self, i):
+        return [self.entry(i, j) for j in range(self.ncol)]
+
+    def get_column(self, j):
+        return [self.entry(i, j) for i in range(self.nrow)]
+
+    def transpose(self) -> "GpuDCRTPolyMatrix":
+        out = GpuDCRTPolyMatrix(self.params, self.ncol, self.nrow, self.level, self.is_ntt)
+        for i in range(self.nrow):
+            for j in range(self.ncol):
+                out.copy_block_from(self, j, i, i, j, 1, 1)
+        return out
+
+    def _same_domain(self, others):
+        for o in others:
+            assert o.params == self.params and o.level == self.level, "concat requires same params/level"
+        return [o.ensure_eval() if self.is_ntt else o.ensure_coeff() for o in others]
+
+    def concat_columns(self, others) -> "GpuDCRTPolyMatrix":
+        others = self._same_domain(others)
+        for o in others:
+            assert o.nrow == self.nrow, "concat_columns requires same row count"
+        ncol = self.ncol + sum(o.ncol for o in others)
+        out = GpuDCRTPolyMatrix(self.params, self.nrow, ncol, self.level, self.is_ntt)
+        off = 0
+        for m in [self] + others:
+            out.copy_block_from(m, 0, off, 0, 0, m.nrow, m.ncol)
+            off += m.ncol
+        out.is_ntt = self.is_ntt
+        return out
+
+    def concat_rows(self, others) -> "GpuDCRTPolyMatrix":
+        others = self._same_domain(others)
+        for o in others:
+            assert o.ncol == self.ncol, "concat_rows requires same column count"
+        nrow = self.nrow + sum(o.nrow for o in others)
+        out = GpuDCRTPolyMatrix(self.params, nrow, self.ncol, self.level, self.is_ntt)
+        off = 0
+        for m in [self] + others:
+            out.copy_block_from(m, off, 0, 0, 0, m.nrow, m.ncol)
+            off += m.nrow
+        out.is_ntt = self.is_ntt
+        return out
+
+    def concat_diag(self, others) -> "GpuDCRTPolyMatrix":
+        others = self._same_domain(others)
+        nrow = self.nrow + sum(o.nrow for o in others)
+        ncol = self.ncol + sum(o.ncol for o in others)
+        out = GpuDCRTPolyMatrix._new_zero_with_state(self.params, nrow, ncol, self.level, self.is_ntt)
+        ro = co = 0
+        for m in [self] + others:
+            out.copy_block_from(m, ro, co, 0, 0, m.nrow, m.ncol)
+            ro += m.nrow
+            co += m.ncol
+        out.is_ntt = self.is_ntt
+        return out
+
+    def tensor(self, other) -> "GpuDCRTPolyMatrix":
+        assert self.params == other.params and self.level == other.level and self.is_ntt == other.is_ntt
+        out = GpuDCRTPolyMatrix(self.params, self.nrow * other.nrow, self.ncol * other.ncol, self.level, self.is_ntt)
+        if 0 in (self.nrow, self.ncol, other.nrow, other.ncol):
+            return out
+        for i in range(self.nrow):
+            for j in range(self.ncol):
+                block = other.mul_scalar(self.entry(i, j))
+                out.copy_block_from(block, i * other.nrow, j * other.ncol, 0, 0, other.nrow, other.ncol)
+        return out
+
+    def vectorize_columns(self) -> "GpuDCRTPolyMatrix":
+        out = GpuDCRTPolyMatrix(self.params, self.nrow * self.ncol, 1, self.level, self.is_ntt)
+        for j in range(self.ncol):
+            out.copy_block_from(self, j * self.nrow, 0, 0, j, self.nrow, 1)
+        return out
+
+    # ------------------------------------------------------------------ arithmetic
+    def _check_binop(self, rhs, what):
+        assert self.params == rhs.params, f"{what} requires same params"
+        assert self.level == rhs.level, f"{what} requires same level"
+        assert self.is_ntt == rhs.is_ntt, f"{what} requires same domain"
+        assert (self.nrow, self.ncol) == (rhs.nrow, rhs.ncol), f"{what} requires same dimensions"
+
+    def add_in_place(self, rhs) -> None:
+        self._check_binop(rhs, "add_in_place")
+        if self.nrow == 0 or self.ncol == 0:
+            return
+        check_status(_ffi.lib().gpu_matrix_add(self.raw, self.raw, rhs.raw), "gpu_matrix_add")
+        self.is_ntt = rhs.is_ntt
+
+    def sub_in_place(self, rhs) -> None:
+        self._check_binop(rhs, "sub_in_place")
+        if self.nrow == 0 or self.ncol == 0:
+            return
+        check_status(_ffi.lib().gpu_matrix_sub(self.raw, self.raw, rhs.raw), "gpu_matrix_sub")
+        self.is_ntt = rhs.is_ntt
+
+    def __add__(self, rhs):
+        out = self.clone()
+        out.add_in_place(rhs)
+        return out
+
+    def __sub__(self, rhs):
+        out = self.clone()
+        out.sub_in_place(rhs)
+        return out
+
+    def __neg__(self):
+        z = GpuDCRTPolyMatrix._new_zero_with_state(self.params, self.nrow, self.ncol, self.level, self.is_ntt)
+        z.sub_in_place(self)
+        return z
+
+    def mul_scalar(self, scalar) -> "GpuDCRTPolyMatrix":
+        """`mul_scalar` (gpu_dcrt_poly.rs:1770-1790)."""
+        s = scalar.inner if hasattr(scalar, "inner") else scalar
+        lhs = self.ensure_eval()
+        s = s.ensure_eval()
+        out = GpuDCRTPolyMatrix(self.params, self.nrow, self.ncol, self.level, True)
+        if self.nrow == 0 or self.ncol == 0:
+            return out
+        check_status(_ffi.lib().gpu_matrix_mul_scalar(out.raw, lhs.raw, s.raw), "gpu_matrix_mul_scalar")
+        return out
+
+    def __mul__(self, rhs):
+        from .poly import GpuDCRTPoly
+
+        if isinstance(rhs, GpuDCRTPoly):
+            return self.mul_scalar(rhs)
+        return self._mul_internal(rhs)
+
+    __matmul__ = __mul__
+
+    def _mul_internal(self, rhs) -> "GpuDCRTPolyMatrix":
+        """`mul_internal` (gpu_dcrt_poly.rs:1792-1815)."""
+        assert self.ncol == rhs.nrow, f"matrix multiply shape mismatch: ({self.nrow},{self.ncol}) x ({rhs.nrow},{rhs.ncol})"
+        assert self.params == rhs.params, "mul requires same params"
+        assert self.level == rhs.level, "mul requires same level"
+        assert self.is_ntt and rhs.is_ntt, "mul requires NTT domain"
+        out = GpuDCRTPolyMatrix(self.params, self.nrow, rhs.ncol, self.level, True)
+        if self.nrow == 0 or rhs.ncol == 0:
+            return out
+        check_status(_ffi.lib().gpu_matrix_mul(out.raw, self.raw, rhs.raw), "gpu_matrix_mul")
+        return out
+
+    def __eq__(self, other):
+        if not isinstance(other, GpuDCRTPolyMatrix):
+            return NotImplemented
+        if (
+            self.params != other.params
+            or (self.nrow, self.ncol) != (other.nrow, other.ncol)
+            or self.level != other.level
+            or self.is_ntt != other.is_ntt
+        ):
+            return False
+        if self.raw.value == other.raw.value:
+            return True
+        eq = C.c_int(0)
+        check_status(_ffi.lib().gpu_matrix_equal(self.raw, other.raw, C.byref(eq)), "gpu_matrix_equal")
+        return eq.value != 0
+
+    __hash__ = None
+
+    # ------------------------------------------------------------------ decomposition
+    def _decompose_from(self, src, out_nrow, small) -> "GpuDCRTPolyMatrix":
+        out = GpuDCRTPolyMatrix.new_empty(self.params, out_nrow, self.ncol)
+        fn = _ffi.lib().gpu_matrix_decompose_base_small if small else _ffi.lib().gpu_matrix_decompose_base
+        check_status(fn(src.raw, self.params.base_bits(), out.raw), "gpu_matrix_decompose_base")
+        return out
+
+    def decompose(self) -> "GpuDCRTPolyMatrix":
+        return self.clone().decompose_owned()
+
+    def decompose_owned(self) -> "GpuDCRTPolyMatrix":
+        self.intt_all_in_place()
+        return self._decompose_from(self, self.nrow * self.params.modulus_digits(), False)
+
+    def small_decompose(self) -> "GpuDCRTPolyMatrix":
+        return self.clone().small_decompose_owned()
+
+    def small_decompose_owned(self) -> "GpuDCRTPolyMatrix":
+        self.intt_all_in_place()
+        k = -(-self.params.crt_bits() // self.params.base_bits())
+        return self._decompose_from(self, self.nrow * k, True)
+
+    @classmethod
+    def small_decomposed_identity_chunk(cls, params, size, chunk_idx, chunk_count, scalar_by_digit):
+        """gpu_dcrt_poly.rs:1296-1326."""
+        assert chunk_count > 0 and len(scalar_by_digit) == chunk_count
+        assert chunk_idx < chunk_count
+        polys = [p.inner.ensure_eval() if hasattr(p, "inner") else p.ensure_eval() for p in scalar_by_digit]
+        row = polys[0].concat_columns(polys[1:]) if len(polys) > 1 else polys[0]
+        out = cls.new_empty(params, size, size)
+        st = _ffi.lib().gpu_matrix_fill_small_decomposed_identity_chunk(out.raw, row.raw, chunk_idx)
+        check_status(st, "gpu_matrix_fill_small_decomposed_identity_chunk")
+        return out
+
+    def mul_tensor_identity(self, other, identity_size) -> "GpuDCRTPolyMatrix":
+        assert self.ncol == other.nrow * identity_size
+        w = other.nrow
+        slices = [self.slice(0, self.nrow, i * w, (i + 1) * w)._mul_internal(other) for i in range(identity_size)]
+        return slices[0].concat_columns(slices[1:])
+
+    def get_column_matrix_decompose(self, j) -> "GpuDCRTPolyMatrix":
+        return self.slice(0, self.nrow, j, j + 1).decompose_owned()
+
+    def mul_tensor_identity_decompose(self, other, identity_size) -> "GpuDCRTPolyMatrix":
+        k = self.params.modulus_digits()
+        assert self.ncol == other.nrow * identity_size * k
+        w = other.nrow * k
+        outs = []
+        for i in range(identity_size):
+            sl = self.slice(0, self.nrow, i * w, (i + 1) * w)
+            for j in range(other.ncol):
+                outs.append(sl._mul_internal(other.get_column_matrix_decompose(j)))
+        return outs[0].concat_columns(outs[1:])
+
+    def mul_decompose(self, other) -> "GpuDCRTPolyMatrix":
+        """S * G^-1(B), column-chunked (gpu_dcrt_poly.rs:1414-1493)."""
+        k = self.params.modulus_digits()
+        assert self.ncol == other.nrow * k
+        assert self.params == other.params
+        ncol = other.ncol
+        out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, ncol)
+        if self.nrow == 0 or ncol == 0:
+            return out
+        width = min(mul_decompose_column_chunk_width(), ncol)
+        for c0 in range(0, ncol, width):
+            c1 = min(c0 + width, ncol)
+            dec = other.slice(0, other.nrow, c0, c1).decompose_owned()
+            prod = self._mul_internal(dec)
+            out.copy_block_from(prod, 0, c0, 0, 0, self.nrow, c1 - c0)
+        return out
+
+    def mul_decompose_small(self, other) -> "GpuDCRTPolyMatrix":
+        k = -(-self.params.crt_bits() // self.params.base_bits())
+        assert self.ncol == other.nrow * k
+        ncol = other.ncol
+        out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, ncol)
+        if self.nrow == 0 or ncol == 0:
+            return out
+        width = min(mul_decompose_column_chunk_width(), ncol)
+        for c0 in range(0, ncol, width):
+            c1 = min(c0 + width, ncol)
+            dec = other.slice(0, other.nrow, c0, c1).small_decompose_owned()
+            prod = self._mul_internal(dec)
+            out.copy_block_from(prod, 0, c0, 0, 0, self.nrow, c1 - c0)
+        return out
+
+    # ------------------------------------------------------------------ sampling entry points
+    @classmethod
+    def sample_distribution(cls, params, nrow, ncol, dist: int, sigma: float, seed: GpuRngSeed):
+        out = cls.new_empty(params, nrow, ncol)
+        if nrow == 0 or ncol == 0:
+            return out
+        check_status(_ffi.lib().gpu_matrix_sample_distribution(out.raw, dist, sigma, seed), "gpu_matrix_sample_distribution")
+        return out
+
+    @classmethod
+    def sample_distribution_columns(cls, params, nrow, total_ncol, col_start, col_len, dist, sigma, seed):
+        assert col_start + col_len <= total_ncol, "sample_distribution_columns range out of bounds"
+        out = cls.new_empty(params, nrow, col_len)
+        if nrow == 0 or col_len == 0:
+            return out
+        st = _ffi.lib().gpu_matrix_sample_distribution_columns(out.raw, dist, sigma, seed, total_ncol, col_start)
+        check_status(st, "gpu_matrix_sample_distribution_columns")
+        return out
+
+    def gauss_samp_gq_arb_base(self, c: float, dgg_stddev: float, seed: GpuRngSeed) -> "GpuDCRTPolyMatrix":
+        """Consumes self (gpu_dcrt_poly.rs:509-528)."""
+        out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow * self.params.modulus_digits(), self.ncol)
+        self.intt_all_in_place()
+        st = _ffi.lib().gpu_matrix_gauss_samp_gq_arb_base(self.raw, self.params.base_bits(), c, dgg_stddev, seed, out.raw)
+        check_status(st, "gpu_matrix_gauss_samp_gq_arb_base")
+        return out
+
+    @staticmethod
+    def create_p1_covariance_cache(a_mat, b_mat, d_mat, sigma, s, dgg_stddev) -> GpuP1CovarianceCache:
+        raw = C.c_void_p()
+        st = _ffi.lib().gpu_matrix_create_p1_covariance_cache(a_mat.raw, b_mat.raw, d_mat.raw, sigma, s, dgg_stddev, C.byref(raw))
+        check_status(st, "gpu_matrix_create_p1_covariance_cache")
+        return GpuP1CovarianceCache(raw)
+
+    @staticmethod
+    def sample_p1_full_cached(cache: GpuP1CovarianceCache, tp2, seed: GpuRngSeed) -> "GpuDCRTPolyMatrix":
+        out = GpuDCRTPolyMatrix.new_empty(tp2.params, tp2.nrow, tp2.ncol)
+        if tp2.nrow == 0 or tp2.ncol == 0:
+            return out
+        tp2.intt_all_in_place()
+        check_status(_ffi.lib().gpu_matrix_sample_p1_full_cached(cache.raw, tp2.raw, seed, out.raw), "gpu_matrix_sample_p1_full_cached")
+        return out
+
+    def __repr__(self):
+        return f"GpuDCRTPolyMatrix({self.nrow}x{self.ncol}, level={self.level}, is_ntt={self.is_ntt})"

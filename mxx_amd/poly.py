@@ -1,0 +1,142 @@
+"""`GpuDCRTPoly` — a polynomial is a 1x1 `GpuDCRTPolyMatrix` (src/poly/dcrt/gpu.rs:707-1100).
+
+`Poly` trait: src/poly/mod.rs:79-198.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .matrix import GpuDCRTPolyMatrix
+from .params import GpuDCRTPolyParams
+
+
+class GpuDCRTPoly:
+    __slots__ = ("inner",)
+
+    def __init__(self, inner: GpuDCRTPolyMatrix):
+        inner_rows, inner_cols = inner.size()
+        assert inner_rows == 1 and inner_cols == 1, "matrix must be 1x1 for poly operation"
+        self.inner = inner
+
+    # ---- constructors --------------------------------------------------------------
+    @classmethod
+    def _from_residues(cls, params: GpuDCRTPolyParams, residues: np.ndarray, eval_format: bool) -> "GpuDCRTPoly":
+        L, n = residues.shape
+        return cls(GpuDCRTPolyMatrix.from_rns(params, residues.reshape(1, 1, L, n), eval_format))
+
+    @classmethod
+    def from_biguints(cls, params, coeffs) -> "GpuDCRTPoly":
+        """Coefficients (python ints) -> COEFF residues -> NTT (gpu.rs:930-933,841-857)."""
+        n = params.ring_dimension()
+        assert len(coeffs) <= n
+        moduli = params.moduli()
+        res = np.zeros((len(moduli), n), dtype=np.uint64)
+        for l, q in enumerate(moduli):
+            res[l, : len(coeffs)] = [int(c) % q for c in coeffs]
+        p = cls._from_residues(params, res, False)
+        p.inner.ntt_all_in_place()
+        return p
+
+    from_coeffs = from_biguints
+
+    @classmethod
+    def from_biguints_eval(cls, params, slots) -> "GpuDCRTPoly":
+        # Rust-side oddity kept as is: slot values are loaded as coefficients and
+        # transformed (gpu.rs:935-939)
+        return cls.from_biguints(params, slots)
+
+    @classmethod
+    def from_u32s(cls, params, coeffs) -> "GpuDCRTPoly":
+        return cls.from_biguints(params, [int(c) for c in coeffs])
+
+    @classmethod
+    def from_bool_vec(cls, params, coeffs) -> "GpuDCRTPoly":
+        return cls.from_biguints(params, [1 if c else 0 for c in coeffs])
+
+    @classmethod
+    def from_biguint_to_constant(cls, params, value: int) -> "GpuDCRTPoly":
+        return cls.from_biguints(params, [value])
+
+    from_usize_to_constant = from_biguint_to_constant
+
+    @classmethod
+    def const_zero(cls, params):
+        return cls.from_biguints(params, [0])
+
+    @classmethod
+    def const_one(cls, params):
+        return cls.from_biguints(params, [1])
+
+    @classmethod
+    def const_minus_one(cls, params):
+        return cls.from_biguints(params, [params.modulus() - 1])
+
+    @classmethod
+    def const_max(cls, params):
+        return cls.from_biguints(params, [params.modulus() - 1] * params.ring_dimension())
+
+    @classmethod
+    def from_power_of_base_to_constant(cls, params, k: int):
+        return cls.from_biguints(params, [1 << (params.base_bits() * k)])
+
+    @classmethod
+    def from_usize_to_lsb(cls, params, value: int):
+        n = params.ring_dimension()
+        return cls.from_biguints(params, [(value >> i) & 1 for i in range(n)])
+
+    # ---- accessors -----------------------------------------------------------------
+    def params(self) -> GpuDCRTPolyParams:
+        return self.inner.params
+
+    def is_ntt(self) -> bool:
+        return self.inner.is_ntt
+
+    def coeffs(self) -> list[int]:
+        return self.inner.coeffs()[0][0]
+
+    def ensure_coeff_domain(self) -> "GpuDCRTPoly":
+        return GpuDCRTPoly(self.inner.ensure_coeff())
+
+    def ensure_eval_domain(self) -> "GpuDCRTPoly":
+        return GpuDCRTPoly(self.inner.ensure_eval())
+
+    def clone(self) -> "GpuDCRTPoly":
+        return GpuDCRTPoly(self.inner.clone())
+
+    def decompose_base(self) -> list["GpuDCRTPoly"]:
+        dec = self.inner.decompose()
+        return [dec.entry(i, 0) for i in range(dec.nrow)]
+
+    # ---- arithmetic -------------------------------------------------------------------
+    def _pair(self, other):
+        assert self.inner.params == other.inner.params
+        a, b = self.inner, other.inner
+        if a.is_ntt != b.is_ntt:
+            a, b = a.ensure_eval(), b.ensure_eval()
+        return a, b
+
+    def __add__(self, other):
+        a, b = self._pair(other)
+        return GpuDCRTPoly(a + b)
+
+    def __sub__(self, other):
+        a, b = self._pair(other)
+        return GpuDCRTPoly(a - b)
+
+    def __neg__(self):
+        return GpuDCRTPoly(-self.inner)
+
+    def __mul__(self, other):
+        if isinstance(other, GpuDCRTPolyMatrix):
+            return other.mul_scalar(self)
+        return GpuDCRTPoly(self.inner.ensure_eval().mul_scalar(other))
+
+    def __eq__(self, other):
+        if not isinstance(other, GpuDCRTPoly):
+            return NotImplemented
+        if self.inner.params != other.inner.params or self.inner.level != other.inner.level:
+            return False
+        # compare across domains by going to COEFF first (gpu.rs:864-879)
+        return self.inner.ensure_coeff() == other.inner.ensure_coeff()
+
+    __hash__ = None

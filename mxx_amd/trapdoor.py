@@ -1,0 +1,136 @@
+"""Trapdoor generation and preimage sampling on the GPU.
+
+Mirrors `GpuDCRTTrapdoor` / `GpuDCRTPolyTrapdoorSampler`
+(src/sampler/trapdoor/gpu.rs:15-474; trait `PolyTrapdoorSampler`,
+src/sampler/mod.rs:122-207) call for call: every step is one C-ABI entry of
+libgpupoly on the context's stream, no host round trip until the caller reads.
+"""
+from __future__ import annotations
+
+import math
+import threading
+
+from .matrix import GpuDCRTPolyMatrix
+from .sampler import DistType, GpuDCRTPolyUniformSampler, random_gpu_rng_seed
+
+SPECTRAL_CONSTANT = 1.8  # trapdoor/gpu.rs:15
+
+
+def preimage_c(base: int, sigma: float) -> float:
+    return (base + 1.0) * sigma
+
+
+def preimage_smoothing_parameter(base: int, sigma: float, d: int, n: int, k: int) -> float:
+    return SPECTRAL_CONSTANT * (base + 1.0) * sigma * sigma * (math.sqrt(d * n * k) + math.sqrt(2 * n) + 4.7)
+
+
+def _coeff_cached(m: GpuDCRTPolyMatrix) -> GpuDCRTPolyMatrix:
+    return m.clone().into_coeff_domain()
+
+
+class GpuDCRTTrapdoor:
+    """R, E ~ D_sigma^{d x dk} plus the coefficient-domain RR^T, RE^T, EE^T caches (gpu.rs:46-80)."""
+
+    def __init__(self, r: GpuDCRTPolyMatrix, e: GpuDCRTPolyMatrix):
+        self.r = r
+        self.e = e
+        rt, et = r.transpose(), e.transpose()
+        self.a_mat_coeff = _coeff_cached(r * rt)
+        self.b_mat_coeff = _coeff_cached(r * et)
+        self.d_mat_coeff = _coeff_cached(e * et)
+        self._p1_cache = None
+        self._p1_lock = threading.Lock()
+
+    @classmethod
+    def new(cls, params, size: int, sigma: float) -> "GpuDCRTTrapdoor":
+        u = GpuDCRTPolyUniformSampler()
+        k = params.modulus_digits()
+        dist = DistType.GaussDist(sigma)
+        return cls(u.sample_uniform(params, size, size * k, dist), u.sample_uniform(params, size, size * k, dist))
+
+    def p1_covariance_cache(self, c: float, s: float, dgg_stddev: float):
+        with self._p1_lock:
+            if self._p1_cache is not None and self._p1_cache[0] == (c, s, dgg_stddev):
+                return self._p1_cache[1]
+            cache = GpuDCRTPolyMatrix.create_p1_covariance_cache(
+                self.a_mat_coeff, self.b_mat_coeff, self.d_mat_coeff, c, s, dgg_stddev
+            )
+            self._p1_cache = ((c, s, dgg_stddev), cache)
+            return cache
+
+    def __eq__(self, other):
+        return isinstance(other, GpuDCRTTrapdoor) and self.r == other.r and self.e == other.e
+
+    __hash__ = None
+
+
+class GpuDCRTPolyTrapdoorSampler:
+    def __init__(self, params, sigma: float):
+        self.sigma = float(sigma)
+        self.base = 1 << params.base_bits()
+        self.c = preimage_c(self.base, self.sigma)
+
+    def trapdoor(self, params, size: int):
+        """A = [A_bar | I | G - (A_bar R + E)] (gpu.rs:202-215)."""
+        u = GpuDCRTPolyUniformSampler()
+        td = GpuDCRTTrapdoor.new(params, size, self.sigma)
+        a_bar = u.sample_uniform(params, size, size, DistType.FinRingDist())
+        g = GpuDCRTPolyMatrix.gadget_matrix(params, size)
+        a0 = a_bar.concat_columns([GpuDCRTPolyMatrix.identity(params, size)])
+        a1 = g - (a_bar * td.r + td.e)
+        return td, a0.concat_columns([a1])
+
+    def _sample_pert(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol):
+        """`sample_pert_square_mat_gpu_native_parts` (gpu.rs:423-474)."""
+        u = GpuDCRTPolyUniformSampler()
+        d, dk = td.r.row_size(), td.r.col_size()
+        padded = -(-total_ncol // d) * d
+        p2 = u.sample_uniform(params, dk, padded, DistType.GaussDist(sigma_large))
+        tp2 = td.r.concat_rows([td.e]) * p2
+        cache = td.p1_covariance_cache(c, s, dgg_stddev)
+        p1 = GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2, random_gpu_rng_seed())
+        return p1, p2
+
+    def preimage(self, params, td: GpuDCRTTrapdoor, public_matrix, target) -> GpuDCRTPolyMatrix:
+        """x with public_matrix * x == target (gpu.rs:228-369)."""
+        d = public_matrix.row_size()
+        target_cols = target.col_size()
+        assert target.row_size() == d, "Target matrix should have the same number of rows as the public matrix"
+        n, k = params.ring_dimension(), params.modulus_digits()
+        s = preimage_smoothing_parameter(self.base, self.sigma, d, n, k)
+        dgg_large_std = math.sqrt(s * s - self.c * self.c)
+        p1, p2 = self._sample_pert(params, td, s, self.c, self.sigma, dgg_large_std, target_cols)
+        p1_rows, p2_rows = p1.row_size(), p2.row_size()
+        assert public_matrix.col_size() == p1_rows + p2_rows, "public matrix columns must match perturbation rows"
+        left = public_matrix.slice(0, d, 0, p1_rows)
+        right = public_matrix.slice(0, d, p1_rows, p1_rows + p2_rows)
+        p_hat_image = (left * p1) + (right * p2)
+        if p_hat_image.col_size() != target_cols:
+            p_hat_image = p_hat_image.slice_columns(0, target_cols)
+        perturbed = target - p_hat_image
+        z_hat = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed())
+        r_z = td.r * z_hat
+        out = GpuDCRTPolyMatrix(params, p1_rows + p2_rows, target_cols, p1.level, p1.is_ntt)
+        out.copy_block_from(p1, 0, 0, 0, 0, p1_rows, target_cols)
+        out.copy_block_from(p2, p1_rows, 0, 0, 0, p2_rows, target_cols)
+        out.add_block_from(r_z, 0, 0, 0, 0, r_z.row_size(), target_cols)
+        e_z = td.e * z_hat
+        out.add_block_from(e_z, d, 0, 0, 0, e_z.row_size(), target_cols)
+        out.add_block_from(z_hat, 2 * d, 0, 0, 0, z_hat.row_size(), target_cols)
+        return out
+
+    def preimage_extend(self, params, td, public_matrix, ext_matrix, target) -> GpuDCRTPolyMatrix:
+        """gpu.rs:399-420."""
+        d = public_matrix.row_size()
+        n, k = params.ring_dimension(), params.modulus_digits()
+        s = preimage_smoothing_parameter(self.base, self.sigma, d, n, k)
+        u = GpuDCRTPolyUniformSampler()
+        right = u.sample_uniform(params, ext_matrix.col_size(), target.col_size(), DistType.GaussDist(s))
+        t = target - (ext_matrix * right)
+        left = self.preimage(params, td, public_matrix, t)
+        return left.concat_rows([right])
+
+    def preimage_batched_sharded(self, requests):
+        """`preimage_batched_sharded` (gpu.rs:371-397): requests = [(entry_idx, params, trapdoor, A, target)];
+        each request runs on the device its params name."""
+        return [(idx, self.preimage(p, td, a, t)) for (idx, p, td, a, t) in requests]

@@ -1,0 +1,275 @@
+"""ctypes front-end of the CPU oracle (oracle/oracle.c, oracle/oracle_sampling.c).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke(); never by the product package `mxx_amd`.
+
+All matrices use the reference's wire layout `[poly][limb][n]` of little-endian
+u64 residues with poly = row*cols + col (src/poly/dcrt/gpu.rs:758-788,
+src/matrix/gpu_dcrt_poly.rs:781-816 of the reference), as numpy uint64 arrays of
+shape (rows, cols, L, n).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle_sampling.c")]
+    if (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    ):
+        subprocess.check_call(
+            ["gcc", "-O3", "-fopenmp", "-fPIC", "-std=gnu11", "-ffp-contract=off", "-shared", "-o", _LIB_PATH]
+            + srcs
+            + ["-lm"]
+        )
+    return _LIB_PATH
+
+
+_lib = None
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        L = _lib
+        L.orc_mulmod.restype = C.c_uint64
+        L.orc_mulmod.argtypes = [C.c_uint64] * 3
+        L.orc_powmod.restype = C.c_uint64
+        L.orc_powmod.argtypes = [C.c_uint64] * 3
+        L.orc_invmod.restype = C.c_uint64
+        L.orc_invmod.argtypes = [C.c_uint64] * 2
+        L.orc_is_prime.restype = C.c_int
+        L.orc_is_prime.argtypes = [C.c_uint64]
+        L.orc_gen_crt_basis.restype = C.c_int
+        L.orc_gen_crt_basis.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _u64p]
+        L.orc_min_primitive_root.restype = C.c_uint64
+        L.orc_min_primitive_root.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_ntt_tables.restype = None
+        L.orc_ntt_tables.argtypes = [C.c_uint64, C.c_uint32, _u64p, _u64p, _u64p]
+        L.orc_ntt.restype = None
+        L.orc_ntt.argtypes = [_u64p, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+        L.orc_matrix_ntt.restype = None
+        L.orc_matrix_ntt.argtypes = [_u64p, C.c_size_t, C.c_uint32, C.c_uint32, _u64p, C.c_int]
+        L.orc_pointwise.restype = None
+        L.orc_pointwise.argtypes = [C.c_int, _u64p, _u64p, _u64p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p]
+        for name in ("orc_matmul", "orc_matmul_fast"):
+            f = getattr(L, name)
+            f.restype = None
+            f.argtypes = [_u64p, _u64p, _u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p]
+        L.orc_negacyclic_schoolbook.restype = None
+        L.orc_negacyclic_schoolbook.argtypes = [_u64p, _u64p, _u64p, C.c_uint32, C.c_uint64]
+        L.orc_decompose.restype = None
+        L.orc_decompose.argtypes = [_u64p, _u64p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p, C.c_uint32, C.c_int]
+        L.orc_fill_gadget.restype = None
+        L.orc_fill_gadget.argtypes = [_u64p, C.c_size_t, C.c_uint32, C.c_uint32, _u64p, C.c_uint32, C.c_int]
+        L.orc_ring_mul_batch.restype = None
+        L.orc_ring_mul_batch.argtypes = [_u64p, _u64p, _u64p, C.c_size_t, C.c_uint32, C.c_uint32, _u64p]
+        L.orc_set_threads.restype = None
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_max_threads.restype = C.c_int
+        L.orc_crt_bits.restype = C.c_uint32
+        L.orc_crt_bits.argtypes = [_u64p, C.c_uint32]
+        _bind_sampling(L)
+    return _lib
+
+
+def _bind_sampling(L):
+    if not hasattr(L, "orc_chacha20_block"):
+        return
+    u32p = C.POINTER(C.c_uint32)
+    L.orc_chacha20_block.restype = None
+    L.orc_chacha20_block.argtypes = [u32p, u32p]
+    L.orc_rng_stream.restype = None
+    L.orc_rng_stream.argtypes = [_u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _u64p, C.c_size_t]
+    L.orc_sample_distribution.restype = None
+    L.orc_sample_distribution.argtypes = [
+        _u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p,
+        C.c_int, C.c_double, _u64p,
+    ]
+    L.orc_karney.restype = None
+    L.orc_karney.argtypes = [_u64p, C.c_uint64, C.c_double, C.c_double, _i64p, C.c_size_t]
+    L.orc_gauss_samp_gq.restype = None
+    L.orc_gauss_samp_gq.argtypes = [
+        _u64p, _u64p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p, C.c_uint32, C.c_double, _u64p,
+    ]
+    L.orc_p1_covariance.restype = None
+    L.orc_p1_covariance.argtypes = [
+        _u64p, _u64p, _u64p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64,
+        C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+    ]
+    L.orc_sample_p1.restype = None
+    L.orc_sample_p1.argtypes = [
+        _u64p, _u64p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p,
+        C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, _u64p,
+    ]
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u64p)
+
+
+def _mod(moduli) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(moduli, dtype=np.uint64))
+
+
+# ----------------------------------------------------------------------------
+# parameters
+# ----------------------------------------------------------------------------
+def gen_crt_basis(n: int, depth: int, bits: int) -> list[int]:
+    out = np.zeros(depth, dtype=np.uint64)
+    rc = lib().orc_gen_crt_basis(n, depth, bits, _p(out))
+    if rc != 0:
+        raise ValueError(f"orc_gen_crt_basis({n},{depth},{bits}) failed: {rc}")
+    return [int(x) for x in out]
+
+
+def min_primitive_root(q: int, order: int) -> int:
+    return int(lib().orc_min_primitive_root(q, order))
+
+
+def ntt_tables(q: int, n: int):
+    fwd = np.zeros(n, dtype=np.uint64)
+    inv = np.zeros(n, dtype=np.uint64)
+    ninv = C.c_uint64(0)
+    lib().orc_ntt_tables(q, n, _p(fwd), _p(inv), C.byref(ninv))
+    return fwd, inv, int(ninv.value)
+
+
+# ----------------------------------------------------------------------------
+# transforms / arithmetic on (rows, cols, L, n) uint64 arrays
+# ----------------------------------------------------------------------------
+def ntt_vec(x: np.ndarray, q: int, inverse: bool = False, plain: bool = False) -> np.ndarray:
+    y = np.ascontiguousarray(x, dtype=np.uint64).copy()
+    lib().orc_ntt(_p(y), y.shape[-1], q, int(inverse), int(plain))
+    return y
+
+
+def matrix_ntt(m: np.ndarray, moduli, inverse: bool = False) -> np.ndarray:
+    y = np.ascontiguousarray(m, dtype=np.uint64).copy()
+    L, n = y.shape[-2], y.shape[-1]
+    polys = y.size // (L * n)
+    lib().orc_matrix_ntt(_p(y), polys, L, n, _p(_mod(moduli)), int(inverse))
+    return y
+
+
+def pointwise(op: str, a: np.ndarray, b: np.ndarray, moduli) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    L, n = a.shape[-2], a.shape[-1]
+    polys = a.size // (L * n)
+    bpolys = b.size // (L * n)
+    assert bpolys in (1, polys)
+    out = np.empty_like(a)
+    lib().orc_pointwise({"add": 0, "sub": 1, "mul": 2}[op], _p(out), _p(a), _p(b), polys, bpolys, L, n, _p(_mod(moduli)))
+    return out
+
+
+def matmul(a: np.ndarray, b: np.ndarray, moduli, fast: bool = False) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    rows, inner, L, n = a.shape
+    inner2, cols, L2, n2 = b.shape
+    assert inner == inner2 and L == L2 and n == n2
+    out = np.zeros((rows, cols, L, n), dtype=np.uint64)
+    f = lib().orc_matmul_fast if fast else lib().orc_matmul
+    f(_p(out), _p(a), _p(b), rows, inner, cols, L, n, _p(_mod(moduli)))
+    return out
+
+
+def negacyclic_schoolbook(a: np.ndarray, b: np.ndarray, q: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros_like(a)
+    lib().orc_negacyclic_schoolbook(_p(out), _p(a), _p(b), a.shape[-1], q)
+    return out
+
+
+def crt_bits(moduli) -> int:
+    m = _mod(moduli)
+    return int(lib().orc_crt_bits(_p(m), len(m)))
+
+
+def digits_per_tower(moduli, base_bits: int) -> int:
+    return -(-crt_bits(moduli) // base_bits)
+
+
+def decompose(src_coeff: np.ndarray, moduli, base_bits: int, small: bool = False) -> np.ndarray:
+    """COEFF in -> COEFF out, (rows*k, cols, L, n)."""
+    src = np.ascontiguousarray(src_coeff, dtype=np.uint64)
+    rows, cols, L, n = src.shape
+    dpt = digits_per_tower(moduli, base_bits)
+    k = dpt if small else dpt * L
+    out = np.zeros((rows * k, cols, L, n), dtype=np.uint64)
+    lib().orc_decompose(_p(out), _p(src), rows, cols, L, n, _p(_mod(moduli)), base_bits, int(small))
+    return out
+
+
+def gadget_matrix(size: int, moduli, n: int, base_bits: int, small: bool = False, eval_format: bool = True) -> np.ndarray:
+    L = len(moduli)
+    dpt = digits_per_tower(moduli, base_bits)
+    k = dpt if small else dpt * L
+    out = np.zeros((size, size * k, L, n), dtype=np.uint64)
+    lib().orc_fill_gadget(_p(out), size, L, n, _p(_mod(moduli)), base_bits, int(small))
+    return matrix_ntt(out, moduli) if eval_format else out
+
+
+def ring_mul_batch(a: np.ndarray, b: np.ndarray, moduli) -> np.ndarray:
+    """c = a*b in R_q for a batch of COEFF polys (consumes copies)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    b = np.ascontiguousarray(b, dtype=np.uint64).copy()
+    L, n = a.shape[-2], a.shape[-1]
+    polys = a.size // (L * n)
+    c = np.empty_like(a)
+    lib().orc_ring_mul_batch(_p(c), _p(a), _p(b), polys, L, n, _p(_mod(moduli)))
+    return c
+
+
+# ----------------------------------------------------------------------------
+# CRT reconstruction (python ints; small cases only)
+# ----------------------------------------------------------------------------
+def crt_reconstruct(residues, moduli) -> int:
+    """residues[l] mod moduli[l] -> integer in [0, Q)  (src/poly/mod.rs:45-76 of the reference)."""
+    Q = 1
+    for q in moduli:
+        Q *= int(q)
+    x = 0
+    for r, q in zip(residues, moduli):
+        q = int(q)
+        Qi = Q // q
+        x += int(r) * Qi * pow(Qi, -1, q)
+    return x % Q
+
+
+def splitmix64(seed: int, count: int) -> np.ndarray:
+    """Synthetic-input generator named by SURVEY.md §8(d)."""
+    out = np.empty(count, dtype=np.uint64)
+    idx = np.arange(1, count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        out[:] = z ^ (z >> np.uint64(31))
+    return out
+
+
+def random_matrix(seed: int, rows: int, cols: int, moduli, n: int) -> np.ndarray:
+    """i.i.d. uniform residues in [0,q_l), layout (rows, cols, L, n)."""
+    L = len(moduli)
+    raw = splitmix64(seed, rows * cols * L * n).reshape(rows, cols, L, n)
+    q = np.asarray(moduli, dtype=np.uint64).reshape(1, 1, L, 1)
+    return raw % q

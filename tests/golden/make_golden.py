@@ -1,0 +1,49 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/oracle.c).
+
+The reference has no golden vectors for this path and cannot be built or imported
+here, so the fixtures are produced by the oracle and every one is
+additionally pinned by a schoolbook negacyclic product in tests/test_oracle.py.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = [
+    # name, n, depth, bits, base_bits  (reference test parameter sets)
+    ("n4_d2_b17_base1", 4, 2, 17, 1),
+    ("n16_d3_b18_base6", 16, 3, 18, 6),
+    ("n128_d2_b16_base4", 128, 2, 16, 4),
+    ("n128_d2_b17_base1", 128, 2, 17, 1),
+    ("n16_d2_b51_base17", 16, 2, 51, 17),
+]
+
+for name, n, depth, bits, base in CASES:
+    moduli = O.gen_crt_basis(n, depth, bits)
+    seed = 0x6D7878 ^ (n * 1000 + bits)
+    a = O.random_matrix(seed, 2, 3, moduli, n)
+    b = O.random_matrix(seed + 1, 3, 2, moduli, n)
+    m = O.random_matrix(seed + 2, 2, 2, moduli, n)
+    a_eval = O.matrix_ntt(a, moduli)
+    b_eval = O.matrix_ntt(b, moduli)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        moduli=np.asarray(moduli, dtype=np.uint64),
+        n=n,
+        base_bits=base,
+        a_coeff=a,
+        a_eval=a_eval,
+        b_eval=b_eval,
+        ab_eval=O.matmul(a_eval, b_eval, moduli),
+        m_coeff=m,
+        m_decomposed=O.decompose(m, moduli, base),
+        gadget_eval=O.gadget_matrix(2, moduli, n, base),
+    )
+    print("wrote", name)

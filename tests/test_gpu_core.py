@@ -1,0 +1,346 @@
+"""GPU parity: deterministic ring-matrix ops through the C ABI vs the CPU oracle.
+
+Bit-exact (integer work).  Shapes follow the reference's own GPU unit tests
+(src/poly/dcrt/gpu.rs tests, src/matrix/gpu_dcrt_poly.rs:1946-2720) plus the
+synthetic configs of BASELINE.json.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_params, rand_matrix
+
+pytestmark = pytest.mark.gpu
+
+# (n, depth, bits, base_bits): u32 and u64 word paths, every NTT kernel family
+PARAM_SETS = [
+    (4, 2, 17, 1),       # DCRTPolyParams::default()
+    (16, 3, 18, 6),
+    (128, 2, 17, 1),     # reference GPU test params
+    (128, 2, 16, 4),
+    (128, 2, 16, 8),
+    (1024, 3, 24, 12),   # tuned LDS kernel, logN=10
+    (4096, 2, 24, 12),   # BASELINE config 0
+    (256, 3, 51, 17),    # u64 words, config-5 style
+    (1024, 5, 51, 17),   # reference norm-test params (u64, tuned kernel)
+]
+
+
+@pytest.mark.parametrize("n,depth,bits,base", PARAM_SETS)
+def test_rns_roundtrip_and_levels(gpu, oracle, n, depth, bits, base):
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    x = rand_matrix(oracle, 1, 2, 3, moduli, n)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, True)
+    assert np.array_equal(m.to_rns(), x)
+    # lower level: only limbs 0..=level
+    lvl = depth - 2
+    if lvl >= 0:
+        xl = x[:, :, : lvl + 1]
+        ml = gpu.GpuDCRTPolyMatrix.from_rns(p, xl, False)
+        assert ml.level == lvl
+        assert np.array_equal(ml.to_rns(), xl)
+        ml.ntt_all_in_place()
+        assert np.array_equal(ml.to_rns(), oracle.matrix_ntt(xl, moduli[: lvl + 1]))
+
+
+@pytest.mark.parametrize("n,depth,bits,base", PARAM_SETS)
+def test_ntt_intt_vs_oracle(gpu, oracle, n, depth, bits, base):
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    x = rand_matrix(oracle, 2, 2, 2, moduli, n)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    ev = m.to_rns()
+    assert np.array_equal(ev, oracle.matrix_ntt(x, moduli))
+    m.ntt_all_in_place()  # idempotent on the tag
+    assert np.array_equal(m.to_rns(), ev)
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+    # worst-case inputs: all q-1, and zero
+    top = np.broadcast_to((np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1), x.shape).copy()
+    mt = gpu.GpuDCRTPolyMatrix.from_rns(p, top, False)
+    mt.ntt_all_in_place()
+    assert np.array_equal(mt.to_rns(), oracle.matrix_ntt(top, moduli))
+
+
+@pytest.mark.parametrize("path", ["generic", "global"])
+@pytest.mark.parametrize("n,depth,bits,base", [(128, 2, 17, 1), (1024, 3, 24, 12), (1024, 5, 51, 17)])
+def test_ntt_alternate_kernels(gpu, oracle, path, n, depth, bits, base):
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    x = rand_matrix(oracle, 3, 1, 3, moduli, n)
+    os.environ["MXX_HIP_NTT_PATH"] = path
+    try:
+        m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+        m.ntt_all_in_place()
+        assert np.array_equal(m.to_rns(), oracle.matrix_ntt(x, moduli))
+        m.intt_all_in_place()
+        assert np.array_equal(m.to_rns(), x)
+    finally:
+        del os.environ["MXX_HIP_NTT_PATH"]
+
+
+def test_ntt_n16384_bench_moduli(gpu, oracle):
+    """The bench ring: n=2^14, 24-bit limbs; every limb of the 15-limb basis once."""
+    n = 16384
+    p = make_params(gpu, oracle, n, 15, 24, 12)
+    moduli = p.moduli()
+    x = rand_matrix(oracle, 4, 1, 2, moduli, n)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), oracle.matrix_ntt(x, moduli))
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+
+
+def test_ntt_n16384_u64(gpu, oracle):
+    n = 16384
+    p = make_params(gpu, oracle, n, 2, 51, 17)
+    moduli = p.moduli()
+    x = rand_matrix(oracle, 5, 1, 2, moduli, n)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), oracle.matrix_ntt(x, moduli))
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+
+
+@pytest.mark.parametrize("n,depth,bits,base", PARAM_SETS)
+def test_add_sub_mul_scalar(gpu, oracle, n, depth, bits, base):
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    a = rand_matrix(oracle, 10, 2, 3, moduli, n)
+    b = rand_matrix(oracle, 11, 2, 3, moduli, n)
+    s = rand_matrix(oracle, 12, 1, 1, moduli, n)
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    gs = gpu.GpuDCRTPolyMatrix.from_rns(p, s, True)
+    assert np.array_equal((ga + gb).to_rns(), oracle.pointwise("add", a, b, moduli))
+    assert np.array_equal((ga - gb).to_rns(), oracle.pointwise("sub", a, b, moduli))
+    assert np.array_equal(ga.mul_scalar(gs).to_rns(), oracle.pointwise("mul", a, s, moduli))
+    # ring axioms of the reference tests (gpu.rs:1258-1323)
+    assert (ga - gb) + gb == ga
+    assert np.array_equal((-ga).to_rns(), oracle.pointwise("sub", np.zeros_like(a), a, moduli))
+    assert ga == ga.clone()
+    assert not (ga == gb)
+
+
+MATMUL_SHAPES = [(1, 1, 1), (1, 3, 5), (2, 2, 2), (3, 5, 4), (4, 7, 9), (5, 3, 17), (1, 30, 12), (8, 8, 8)]
+
+
+@pytest.mark.parametrize("shape", MATMUL_SHAPES)
+@pytest.mark.parametrize("n,depth,bits,base", [(16, 3, 18, 6), (128, 2, 16, 4), (256, 3, 51, 17), (4, 2, 17, 1), (64, 2, 30, 10)])
+def test_matmul_vs_oracle(gpu, oracle, shape, n, depth, bits, base):
+    r, k, c = shape
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    a = rand_matrix(oracle, 20, r, k, moduli, n)
+    b = rand_matrix(oracle, 21, k, c, moduli, n)
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+
+
+def test_matmul_worst_case_accumulation(gpu, oracle):
+    """all residues = q-1, inner dimension past the lazy-accumulation window of 31-bit primes."""
+    n = 16
+    moduli = oracle.gen_crt_basis(n, 2, 31)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 8)
+    k = 37
+    top = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1)
+    a = np.broadcast_to(top, (2, k, len(moduli), n)).copy()
+    b = np.broadcast_to(top, (k, 3, len(moduli), n)).copy()
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+
+
+def test_matmul_is_ring_product(gpu, oracle):
+    """1x1 * 1x1 in EVAL == schoolbook negacyclic product of the coefficient forms."""
+    n = 128
+    p = make_params(gpu, oracle, n, 2, 17, 1)
+    moduli = p.moduli()
+    a = rand_matrix(oracle, 30, 1, 1, moduli, n)
+    b = rand_matrix(oracle, 31, 1, 1, moduli, n)
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, False)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, False)
+    ga.ntt_all_in_place()
+    gb.ntt_all_in_place()
+    c = (ga * gb).to_coeff_rns()
+    for l, q in enumerate(moduli):
+        assert np.array_equal(c[0, 0, l], oracle.negacyclic_schoolbook(a[0, 0, l], b[0, 0, l], q))
+
+
+def test_golden_fixtures_on_gpu(gpu, oracle):
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    for f in sorted(os.listdir(gdir)):
+        if not f.endswith(".npz"):
+            continue
+        z = np.load(os.path.join(gdir, f))
+        moduli = [int(q) for q in z["moduli"]]
+        n, base = int(z["n"]), int(z["base_bits"])
+        p = gpu.GpuDCRTPolyParams(n, moduli, base)
+        a = gpu.GpuDCRTPolyMatrix.from_rns(p, z["a_coeff"], False)
+        a.ntt_all_in_place()
+        assert np.array_equal(a.to_rns(), z["a_eval"]), f
+        b = gpu.GpuDCRTPolyMatrix.from_rns(p, z["b_eval"], True)
+        assert np.array_equal((a * b).to_rns(), z["ab_eval"]), f
+        m = gpu.GpuDCRTPolyMatrix.from_rns(p, z["m_coeff"], False)
+        assert np.array_equal(m.decompose().to_coeff_rns(), z["m_decomposed"]), f
+        assert np.array_equal(gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 2).to_rns(), z["gadget_eval"]), f
+
+
+@pytest.mark.parametrize("n,depth,bits,base", [(16, 2, 17, 1), (128, 2, 16, 4), (128, 2, 16, 8), (16, 3, 17, 5), (64, 2, 51, 17), (1024, 3, 24, 12)])
+def test_decompose_and_gadget(gpu, oracle, n, depth, bits, base):
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    M = rand_matrix(oracle, 40, 2, 3, moduli, n)
+    gm = gpu.GpuDCRTPolyMatrix.from_rns(p, M, False)
+    gm_eval = gm.ensure_eval()
+    dec = gm_eval.decompose()  # EVAL in -> EVAL out
+    want = oracle.decompose(M, moduli, base)
+    assert dec.is_ntt
+    assert np.array_equal(dec.to_coeff_rns(), want)
+    assert np.array_equal(gm.decompose().to_coeff_rns(), want)  # COEFF in
+    G = gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 2)
+    assert G.size() == (2, 2 * p.modulus_digits())
+    assert np.array_equal(G.to_rns(), oracle.gadget_matrix(2, moduli, n, base))
+    # G * G^-1(M) == M   (gpu_dcrt_poly.rs:2075-2163)
+    assert G * dec == gm_eval
+    # small variants
+    Gs = gpu.GpuDCRTPolyMatrix.small_gadget_matrix(p, 2)
+    assert np.array_equal(Gs.to_rns(), oracle.gadget_matrix(2, moduli, n, base, small=True))
+    sd = gm.small_decompose()
+    assert np.array_equal(sd.to_coeff_rns(), oracle.decompose(M, moduli, base, small=True))
+
+
+def test_small_decomposed_identity_chunk(gpu, oracle):
+    """chunked == full (gpu_dcrt_poly.rs:2225-2334)."""
+    n, base = 16, 4
+    p = make_params(gpu, oracle, n, 2, 16, base)
+    k = -(-p.crt_bits() // base)
+    size = 3
+    scalar = gpu.GpuDCRTPoly.from_biguints(p, [5, 1, 7, 300])
+    full = gpu.GpuDCRTPolyMatrix.identity(p, size, scalar).small_decompose()
+    digits = scalar.inner.small_decompose()  # k x 1
+    scalar_by_digit = [digits.entry(d, 0) for d in range(k)]
+    for chunk in range(k):
+        got = gpu.GpuDCRTPolyMatrix.small_decomposed_identity_chunk(p, size, chunk, k, scalar_by_digit)
+        want = full.slice(chunk * size, (chunk + 1) * size, 0, size)
+        assert got == want
+
+
+def test_structure_ops(gpu, oracle):
+    n = 16
+    p = make_params(gpu, oracle, n, 3, 18, 6)
+    moduli = p.moduli()
+    a = rand_matrix(oracle, 50, 3, 4, moduli, n)
+    b = rand_matrix(oracle, 51, 3, 2, moduli, n)
+    c = rand_matrix(oracle, 52, 2, 4, moduli, n)
+    ga, gb, gc = (gpu.GpuDCRTPolyMatrix.from_rns(p, x, True) for x in (a, b, c))
+    assert np.array_equal(ga.slice(1, 3, 1, 4).to_rns(), a[1:3, 1:4])
+    assert np.array_equal(ga.transpose().to_rns(), a.transpose(1, 0, 2, 3))
+    assert np.array_equal(ga.concat_columns([gb]).to_rns(), np.concatenate([a, b], axis=1))
+    assert np.array_equal(ga.concat_rows([gc]).to_rns(), np.concatenate([a, c], axis=0))
+    diag = ga.concat_diag([gb]).to_rns()
+    assert np.array_equal(diag[:3, :4], a) and np.array_equal(diag[3:, 4:], b)
+    assert not diag[:3, 4:].any() and not diag[3:, :4].any()
+    assert np.array_equal(ga.vectorize_columns().to_rns()[:, 0], a.transpose(1, 0, 2, 3).reshape(12, 3, n))
+    # add_block / copy_block
+    out = ga.clone()
+    out.add_block_from(gc, 1, 0, 0, 0, 2, 4)
+    want = a.copy()
+    want[1:3] = oracle.pointwise("add", a[1:3], c, moduli)
+    assert np.array_equal(out.to_rns(), want)
+    out.copy_block_from(gb, 0, 2, 1, 0, 2, 2)
+    want[0:2, 2:4] = b[1:3]
+    assert np.array_equal(out.to_rns(), want)
+    # identity and tensor
+    I = gpu.GpuDCRTPolyMatrix.identity(p, 3)
+    assert I * ga == ga
+    t = I.tensor(gb).to_rns()
+    for i in range(3):
+        assert np.array_equal(t[3 * i : 3 * i + 3, 2 * i : 2 * i + 2], b)
+    z = gpu.GpuDCRTPolyMatrix.zero(p, 2, 2)
+    assert not z.to_rns().any()
+    # entry / set_entry / const coeff
+    e = ga.entry(2, 1)
+    assert np.array_equal(e.inner.to_rns()[0, 0], a[2, 1])
+    out2 = ga.clone()
+    out2.set_entry(0, 0, e)
+    assert np.array_equal(out2.to_rns()[0, 0], a[2, 1])
+    coeff = ga.ensure_coeff()
+    assert np.array_equal(coeff.store_const_coeff_words(), coeff.to_rns()[..., 0])
+
+
+def test_mul_decompose_and_tensor_identity(gpu, oracle):
+    n, base = 16, 6
+    p = make_params(gpu, oracle, n, 3, 18, base)
+    moduli = p.moduli()
+    k = p.modulus_digits()
+    S = rand_matrix(oracle, 60, 2, 3 * k, moduli, n)
+    B = rand_matrix(oracle, 61, 3, 4, moduli, n)
+    gs = gpu.GpuDCRTPolyMatrix.from_rns(p, S, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, B, True)
+    want = oracle.matmul(S, oracle.matrix_ntt(oracle.decompose(oracle.matrix_ntt(B, moduli, inverse=True), moduli, base), moduli), moduli)
+    assert np.array_equal(gs.mul_decompose(gb).to_rns(), want)
+    os.environ["MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"] = "3"
+    try:
+        assert np.array_equal(gs.mul_decompose(gb).to_rns(), want)
+    finally:
+        del os.environ["MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"]
+    # mul_tensor_identity: S' * (I_2 (x) B')
+    S2 = rand_matrix(oracle, 62, 2, 6, moduli, n)
+    gs2 = gpu.GpuDCRTPolyMatrix.from_rns(p, S2, True)
+    want2 = np.concatenate([oracle.matmul(S2[:, 0:3], B, moduli), oracle.matmul(S2[:, 3:6], B, moduli)], axis=1)
+    assert np.array_equal(gs2.mul_tensor_identity(gb, 2).to_rns(), want2)
+
+
+def test_poly_wrappers(gpu, oracle):
+    """from_coeffs -> coeffs round trip and cross-domain equality (gpu.rs:1239-1337)."""
+    n = 16
+    p = make_params(gpu, oracle, n, 3, 18, 6)
+    Q = p.modulus()
+    rng = np.random.default_rng(3)
+    coeffs = [int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**62)) % Q for _ in range(n)]
+    poly = gpu.GpuDCRTPoly.from_biguints(p, coeffs)
+    assert poly.is_ntt()
+    assert poly.coeffs() == coeffs
+    assert poly.ensure_coeff_domain() == poly
+    one = gpu.GpuDCRTPoly.const_one(p)
+    assert (poly * one) == poly
+    assert (poly + gpu.GpuDCRTPoly.const_zero(p)) == poly
+    assert ((poly - poly).coeffs()) == [0] * n
+    m1 = gpu.GpuDCRTPoly.const_minus_one(p)
+    assert (poly * m1) == -poly
+
+
+def test_error_behaviour(gpu, oracle):
+    """Non-zero status -> exception with the reference's message shape (gpu.rs:249-263)."""
+    n = 16
+    p = make_params(gpu, oracle, n, 3, 18, 6)
+    moduli = p.moduli()
+    a = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 70, 2, 2, moduli, n), False)
+    b = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 71, 2, 2, moduli, n), True)
+    from mxx_amd import _ffi
+    import ctypes as C
+
+    out = gpu.GpuDCRTPolyMatrix.new_empty(p, 2, 2)
+    assert _ffi.lib().gpu_matrix_mul(out.raw, a.raw, b.raw) != 0
+    assert "requires Eval format" in _ffi.last_error_string()
+    assert _ffi.lib().gpu_matrix_mul_scalar(out.raw, a.raw, b.raw) != 0
+    buf = np.zeros((2, 2, 3, n), dtype=np.uint64)
+    ev = C.c_void_p()
+    st = _ffi.lib().gpu_matrix_store_rns_batch(a.raw, buf.ctypes.data, 3 * n * 8, _ffi.GPU_POLY_FORMAT_EVAL, C.byref(ev))
+    assert st != 0 and "format conversion is not supported" in _ffi.last_error_string()
+    st = _ffi.lib().gpu_matrix_store_const_coeff_batch(b.raw, buf.ctypes.data, 3, C.byref(ev))
+    assert st != 0
+    # equal: mismatching format is "not equal", not an error
+    eq = C.c_int(7)
+    assert _ffi.lib().gpu_matrix_equal(a.raw, b.raw, C.byref(eq)) == 0 and eq.value == 0
+    with pytest.raises(AssertionError):
+        gpu.GpuDCRTPolyMatrix(p, 1, 1, 5, True)  # invalid level (gpu_dcrt_poly.rs:229)
+    raw = C.c_void_p()
+    assert _ffi.lib().gpu_matrix_create(p.ctx_raw(), 5, 1, 1, 1, C.byref(raw)) != 0

@@ -1,0 +1,58 @@
+"""CPU-only: host-side logic of the mirror package (no GPU calls)."""
+import hashlib
+
+import pytest
+
+import mxx_amd as mx
+from mxx_amd import trapdoor as td
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("n,depth,bits", [(4, 2, 17), (128, 2, 16), (16384, 15, 24), (256, 3, 51), (1024, 5, 51)])
+def test_product_basis_equals_oracle_basis(n, depth, bits):
+    assert mx.gen_crt_basis(n, depth, bits) == O.gen_crt_basis(n, depth, bits)
+
+
+def test_cpu_params_derived_quantities():
+    p = mx.DCRTPolyParams(16384, 15, 24, 12)
+    assert p.modulus_digits() == 30  # bench_matrix_mul: k = 15 * ceil(24/12)
+    assert 15 * 24 - 1 <= p.modulus_bits() <= 15 * 24
+    assert p.decompose_last_mask() is None
+    p2 = mx.DCRTPolyParams(16, 3, 17, 5)
+    assert p2.modulus_digits() == 12 and p2.decompose_last_mask() == (1 << 2) - 1
+    d = mx.DCRTPolyParams()
+    assert (d.ring_dimension(), d.crt_depth(), d.crt_bits(), d.base_bits()) == (4, 2, 17, 1)
+    assert d.modulus_digits() == 34  # gadget cols == size*modulus_bits for base 1 (gpu_dcrt_poly.rs:2038-2046)
+
+
+def test_hash_seed_is_deterministic_and_domain_separated():
+    k = bytes(range(32))
+    s1 = mx.hash_seed_for_matrix(k, b"tag")
+    s2 = mx.hash_seed_for_matrix(k, b"tag")
+    s3 = mx.hash_seed_for_matrix(k, b"tag2")
+    assert s1.to_bytes() == s2.to_bytes() != s3.to_bytes()
+    h = hashlib.sha3_256(b"GpuDCRTPolyHashSampler/v2" + k + b"tag" + (0).to_bytes(4, "little")).digest()
+    assert s1.to_bytes() == h
+
+
+def test_seed_word_layout():
+    s = mx.GpuRngSeed.from_bytes(bytes(range(32)))
+    assert s.words[0] == int.from_bytes(bytes(range(8)), "little")
+    assert s.words[3] == int.from_bytes(bytes(range(24, 32)), "little")
+
+
+def test_preimage_constants():
+    # s = 1.8 (b+1) sigma^2 (sqrt(dnk)+sqrt(2n)+4.7), c = (b+1) sigma (trapdoor/gpu.rs:15-27)
+    base, sigma, d, n, k = 1 << 12, 4.578, 1, 16384, 20
+    c = td.preimage_c(base, sigma)
+    s = td.preimage_smoothing_parameter(base, sigma, d, n, k)
+    assert c == (base + 1.0) * sigma
+    assert abs(s - 1.8 * (base + 1) * sigma * sigma * ((d * n * k) ** 0.5 + (2 * n) ** 0.5 + 4.7)) < 1e-6 * s
+    assert s > c
+
+
+def test_dist_type_ffi_codes():
+    assert mx.DistType.FinRingDist().as_ffi() == 0
+    assert mx.DistType.GaussDist(3.2).as_ffi() == 1
+    assert mx.DistType.BitDist().as_ffi() == 2
+    assert mx.DistType.TernaryDist().as_ffi() == 3
