@@ -23,6 +23,9 @@ struct LimbConst {
     uint64_t mu64;       // floor(2^64/q) (u32 path: lazy 64-bit sum reduction)
     uint64_t n_inv;      // N^-1 mod q
     uint64_t n_inv_sh;   // Shoup companion of n_inv (2^32 or 2^64 scaled, by word width)
+    uint64_t mu32;       // floor(2^32/q) (u32 path: fold lazy NTT values back to [0,2q))
+    uint64_t inv_last_w;     // inv[1] * N^-1 mod q : last inverse-NTT stage with N^-1 folded in
+    uint64_t inv_last_w_sh;  // its Shoup companion
     uint32_t kbits;      // bits(q)
     uint32_t lazy_terms; // how many q^2-bounded products fit the accumulator
 };
@@ -46,6 +49,9 @@ struct GpuContext {
     void *d_tw_fwd_sh = nullptr;   // Shoup companions
     void *d_tw_inv = nullptr;      // inv[bitrev(i)] = psi^-i
     void *d_tw_inv_sh = nullptr;
+    void *d_tw2_fwd = nullptr;     // [limb][N] pairs {-w mod 2^W, Shoup(w)} for the lazy forward kernel
+    void *d_tw2_inv = nullptr;     // [limb][N] pairs {w, Shoup(w)} for the lazy inverse kernel
+    bool lazy_ok = false;          // every modulus < 2^(W-7): lazy LDS kernels are valid
     uint64_t *d_garner = nullptr;  // [limb][limb] : inverse of q_j mod q_i for j<i
     std::vector<uint64_t> garner_inv;  // host copy
     std::vector<LimbConst> limbs;      // host copy
@@ -112,6 +118,9 @@ int matrix_check_same_shape(const GpuMatrix *a, const GpuMatrix *b, const char *
 
 // internal launchers shared across translation units
 int launch_ntt(GpuContext *ctx, void *data, size_t vectors, int limbs_per_poly, bool inverse);
+// tuned LDS kernels (ntt_lds_u32.hip / ntt_lds_u64.hip); return -1 when no tuned kernel covers logN
+int launch_ntt_lds_u32(GpuContext *ctx, uint32_t *data, size_t vectors, uint32_t L, bool inverse);
+int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t L, bool inverse);
 int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
 int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,
                       size_t src_col, size_t rows, size_t cols, bool add);

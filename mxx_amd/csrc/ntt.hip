@@ -10,181 +10,15 @@
 // cuda/src/matrix/MatrixNTT.cu:787-811 (2 + log2 N launches and ~17 HBM round
 // trips per transform there; one launch and one HBM round trip here).
 //
-// Structure of the LDS kernel (LOGN stages split into passes of <= LOGR stages):
-//   HBM --16 B/lane coalesced--> LDS | pass 0 | pass 1 | ... | --> HBM
-// In each pass a thread pulls 2^LOGR residues that form closed butterfly
-// networks into registers, runs up to LOGR radix-2 stages on them with Shoup
-// multiplications (twiddle and its companion floor(w*2^W/q) from an L2-resident
-// table), and puts them back in place; one barrier per pass.
+// Three kernel families, all bit-identical to the CPU oracle:
+//   * ntt_lds.h        : tuned lazy-butterfly LDS kernels, logN in [10,15] (hot path)
+//   * generic (below)  : any logN that fits LDS, one radix-2 stage per barrier
+//   * global (below)   : vectors larger than LDS, one stage per launch
 #include "common.h"
 #include "modarith.h"
 
 #include <atomic>
 #include <cstdlib>
-
-template <typename W>
-struct Vec16;
-template <>
-struct Vec16<uint32_t> {
-    typedef uint4 type;
-    static constexpr int n = 4;
-};
-template <>
-struct Vec16<uint64_t> {
-    typedef ulonglong2 type;
-    static constexpr int n = 2;
-};
-
-// LDS index padding: +4 words per 32 and +16 words per 512 keeps the strided pass
-// reads (stride 16/512 words) and the contiguous 16-byte reads mostly conflict-free.
-__device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + ((e >> 5) << 2) + ((e >> 9) << 4); }
-static inline size_t lds_padded_words(size_t n) { return n + ((n >> 5) << 2) + ((n >> 9) << 4) + 16; }
-
-template <typename W, int C, bool INV>
-__device__ __forceinline__ void butterfly_network(W (&v)[1 << C], const W *__restrict__ tw,
-                                                  const W *__restrict__ tws, uint32_t bi, int s_p, W q) {
-    if (!INV) {
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const int half = 1 << (C - k - 1);
-            const uint32_t tb = (1u << (s_p + k)) + (bi << k);
-#pragma unroll
-            for (int u = 0; u < (1 << C); ++u) {
-                if (u & half) continue;
-                const uint32_t idx = tb + (static_cast<uint32_t>(u) >> (C - k));
-                const W w = tw[idx], ws = tws[idx];
-                const W U = v[u];
-                const W V = mul_shoup<W>(v[u + half], w, ws, q);
-                v[u] = add_mod<W>(U, V, q);
-                v[u + half] = sub_mod<W>(U, V, q);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int k = C - 1; k >= 0; --k) {
-            const int half = 1 << (C - k - 1);
-            const uint32_t tb = (1u << (s_p + k)) + (bi << k);
-#pragma unroll
-            for (int u = 0; u < (1 << C); ++u) {
-                if (u & half) continue;
-                const uint32_t idx = tb + (static_cast<uint32_t>(u) >> (C - k));
-                const W w = tw[idx], ws = tws[idx];
-                const W U = v[u];
-                const W V = v[u + half];
-                v[u] = add_mod<W>(U, V, q);
-                v[u + half] = mul_shoup<W>(sub_mod<W>(U, V, q), w, ws, q);
-            }
-        }
-    }
-}
-
-// one pass over the LDS-resident vector: stages [S_P, S_P + C)
-template <typename W, int LOGN, int LOGR, int S_P, int C, bool INV>
-__device__ __forceinline__ void lds_pass(W *__restrict__ x, const W *__restrict__ tw, const W *__restrict__ tws, W q,
-                                         uint32_t tid) {
-    constexpr uint32_t B = 1u << (LOGN - S_P);  // sub-problem size at this pass
-    constexpr uint32_t S = B >> C;              // element stride inside a butterfly set
-    constexpr int G = 1 << (LOGR - C);          // sets per thread
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const uint32_t sigma = tid * G + g;
-        const uint32_t bi = sigma / S;
-        const uint32_t r = sigma - bi * S;
-        const uint32_t base = bi * B + r;
-        W v[1 << C];
-#pragma unroll
-        for (int u = 0; u < (1 << C); ++u) v[u] = x[lds_pad(base + S * u)];
-        butterfly_network<W, C, INV>(v, tw, tws, bi, S_P, q);
-#pragma unroll
-        for (int u = 0; u < (1 << C); ++u) x[lds_pad(base + S * u)] = v[u];
-    }
-}
-
-template <typename W, int LOGN, int LOGR, bool INV>
-__global__ void __launch_bounds__(1 << (LOGN - LOGR))
-    ntt_lds_kernel(W *__restrict__ data, const W *__restrict__ tw_all, const W *__restrict__ tws_all,
-                   const LimbConst *__restrict__ limbs, uint32_t L) {
-    constexpr uint32_t N = 1u << LOGN;
-    constexpr uint32_t T = 1u << (LOGN - LOGR);
-    constexpr int P = (LOGN + LOGR - 1) / LOGR;
-    constexpr int CLAST = LOGN - (P - 1) * LOGR;
-    static_assert(P >= 2 && P <= 4, "pass count");
-    typedef typename Vec16<W>::type V16;
-    constexpr int VN = Vec16<W>::n;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    W *x = reinterpret_cast<W *>(smem);
-
-    const uint32_t tid = threadIdx.x;
-    const size_t vec = blockIdx.x;
-    const uint32_t limb = static_cast<uint32_t>(vec % L);
-    const W q = static_cast<W>(limbs[limb].q);
-    const W *tw = tw_all + static_cast<size_t>(limb) * N;
-    const W *tws = tws_all + static_cast<size_t>(limb) * N;
-    W *g = data + vec * N;
-
-    // HBM -> LDS, 16 bytes per lane, fully coalesced
-#pragma unroll
-    for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
-        const uint32_t i = tid + jj * T;
-        V16 val = reinterpret_cast<const V16 *>(g)[i];
-        *reinterpret_cast<V16 *>(&x[lds_pad(i * VN)]) = val;
-    }
-    __syncthreads();
-
-    if (!INV) {
-        lds_pass<W, LOGN, LOGR, 0, LOGR, false>(x, tw, tws, q, tid);
-        __syncthreads();
-        if constexpr (P == 2) {
-            lds_pass<W, LOGN, LOGR, LOGR, CLAST, false>(x, tw, tws, q, tid);
-        } else if constexpr (P == 3) {
-            lds_pass<W, LOGN, LOGR, LOGR, LOGR, false>(x, tw, tws, q, tid);
-            __syncthreads();
-            lds_pass<W, LOGN, LOGR, 2 * LOGR, CLAST, false>(x, tw, tws, q, tid);
-        } else {
-            lds_pass<W, LOGN, LOGR, LOGR, LOGR, false>(x, tw, tws, q, tid);
-            __syncthreads();
-            lds_pass<W, LOGN, LOGR, 2 * LOGR, LOGR, false>(x, tw, tws, q, tid);
-            __syncthreads();
-            lds_pass<W, LOGN, LOGR, 3 * LOGR, CLAST, false>(x, tw, tws, q, tid);
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
-            const uint32_t i = tid + jj * T;
-            V16 val = *reinterpret_cast<const V16 *>(&x[lds_pad(i * VN)]);
-            reinterpret_cast<V16 *>(g)[i] = val;
-        }
-    } else {
-        if constexpr (P == 2) {
-            lds_pass<W, LOGN, LOGR, LOGR, CLAST, true>(x, tw, tws, q, tid);
-        } else if constexpr (P == 3) {
-            lds_pass<W, LOGN, LOGR, 2 * LOGR, CLAST, true>(x, tw, tws, q, tid);
-            __syncthreads();
-            lds_pass<W, LOGN, LOGR, LOGR, LOGR, true>(x, tw, tws, q, tid);
-        } else {
-            lds_pass<W, LOGN, LOGR, 3 * LOGR, CLAST, true>(x, tw, tws, q, tid);
-            __syncthreads();
-            lds_pass<W, LOGN, LOGR, 2 * LOGR, LOGR, true>(x, tw, tws, q, tid);
-            __syncthreads();
-            lds_pass<W, LOGN, LOGR, LOGR, LOGR, true>(x, tw, tws, q, tid);
-        }
-        __syncthreads();
-        lds_pass<W, LOGN, LOGR, 0, LOGR, true>(x, tw, tws, q, tid);
-        __syncthreads();
-        const W ninv = static_cast<W>(limbs[limb].n_inv);
-        const W ninv_sh = static_cast<W>(limbs[limb].n_inv_sh);
-#pragma unroll
-        for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
-            const uint32_t i = tid + jj * T;
-            V16 val = *reinterpret_cast<const V16 *>(&x[lds_pad(i * VN)]);
-            W *e = reinterpret_cast<W *>(&val);
-#pragma unroll
-            for (int j = 0; j < VN; ++j) e[j] = mul_shoup<W>(e[j], ninv, ninv_sh, q);
-            reinterpret_cast<V16 *>(g)[i] = val;
-        }
-    }
-}
 
 // Any logN whose vector fits LDS: one radix-2 stage per barrier (small / odd sizes).
 template <typename W, bool INV>
@@ -280,23 +114,6 @@ __global__ void ntt_scale_global_kernel(W *__restrict__ data, const LimbConst *_
 // ---- host-side dispatch -------------------------------------------------------------------
 static constexpr size_t kMaxLdsBytes = 160 * 1024;
 
-template <typename W, int LOGN, int LOGR, bool INV>
-static int launch_lds(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
-    auto kern = ntt_lds_kernel<W, LOGN, LOGR, INV>;
-    const size_t lds = lds_padded_words(size_t(1) << LOGN) * sizeof(W);
-    static std::atomic<uint64_t> configured_mask{0};
-    if (lds > 64 * 1024 && !(configured_mask.load() & (1ull << (ctx->device & 63)))) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(lds)));
-        configured_mask.fetch_or(1ull << (ctx->device & 63));
-    }
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(vectors)), dim3(1u << (LOGN - LOGR)), lds, ctx->stream, data,
-                       static_cast<const W *>(INV ? ctx->d_tw_inv : ctx->d_tw_fwd),
-                       static_cast<const W *>(INV ? ctx->d_tw_inv_sh : ctx->d_tw_fwd_sh), ctx->d_limbs, L);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 template <typename W, bool INV>
 static int launch_generic(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
     const uint32_t logN = ctx->logN;
@@ -361,18 +178,11 @@ static int launch_ntt_typed(GpuContext *ctx, W *data, size_t vectors, uint32_t L
     const size_t N = size_t(1) << logN;
     const int force = ntt_path_override();
     const bool fits_generic = N * sizeof(W) <= kMaxLdsBytes && logN >= 1;
-    const bool fits_tuned = lds_padded_words(N) * sizeof(W) <= kMaxLdsBytes;
-    if (force == 3 || !fits_generic) return launch_global<W, INV>(ctx, data, vectors, L);
-    if (force != 2 && fits_tuned) {
-        switch (logN) {
-            case 10: return launch_lds<W, 10, 4, INV>(ctx, data, vectors, L);
-            case 11: return launch_lds<W, 11, 4, INV>(ctx, data, vectors, L);
-            case 12: return launch_lds<W, 12, 4, INV>(ctx, data, vectors, L);
-            case 13: return launch_lds<W, 13, 5, INV>(ctx, data, vectors, L);
-            case 14: return launch_lds<W, 14, 5, INV>(ctx, data, vectors, L);
-            case 15: return launch_lds<W, 15, 5, INV>(ctx, data, vectors, L);
-            default: break;
-        }
+    if (force != 2 && ctx->lazy_ok) {
+        int rc;
+        if constexpr (sizeof(W) == 4) rc = launch_ntt_lds_u32(ctx, data, vectors, L, INV);
+        else rc = launch_ntt_lds_u64(ctx, data, vectors, L, INV);
+        if (rc >= 0) return rc;  // -1: no tuned kernel for this logN
     }
     return launch_generic<W, INV>(ctx, data, vectors, L);
 }

@@ -1,0 +1,273 @@
+// ntt_lds.h — the tuned, LDS-resident negacyclic NTT / INTT kernels (one workgroup per
+// (polynomial, RNS limb) vector), with lazy (Harvey-style) butterflies.
+//
+// gfx950 issues an integer wave64 VALU instruction in ~4 cycles per SIMD (measured,
+// tools/valu_rates.hip: v_mul_hi_u32 4.8, v_mul_u32_u24 4.0, v_sub+v_min 8.2 for two),
+// so a 2^14-point transform is VALU-bound unless a butterfly costs <= ~6 instructions.
+// The butterflies therefore keep values in redundant form:
+//   forward (Cooley-Tukey):  nT = V*(-w) + hi(V*w')*q   (== -(V*w mod q), |.| < 2q)
+//                            A = U - nT ; B = U + 2q + nT            -> 5 VALU ops
+//       bounds only grow by 2q per stage, so no correction until the very end
+//       ((1 + 2 logN) q < 2^W needs q < 2^(W-5)).
+//   inverse (Gentleman-Sande): A = X + Y ; D = X + M - Y ; B = D*w - hi(D*w')*q  -> 6 ops
+//       with M = the compile-time bound of Y; A doubles its bound per stage, so each
+//       pass (<= 5 stages) ends with one mulhi-based fold back to [0, 2q) of the
+//       elements that need it (2^(c+1) q < 2^W needs q < 2^(W-6)).
+//   N^-1 is folded into the last inverse stage's twiddle.
+// Same transform as ntt_generic_kernel (OpenFHE convention, see ntt.hip); outputs are
+// canonical residues, bit-identical to the CPU oracle.
+#pragma once
+
+#include "common.h"
+#include "modarith.h"
+
+template <typename W>
+struct TwPair {  // twiddle (negated for the forward transform) + Shoup companion, one load
+    W w;
+    W ws;
+};
+
+// LDS index padding (in words): +4 per 32, +16 per 512.
+__host__ __device__ constexpr uint32_t lds_pad_c(uint32_t e) { return e + ((e >> 5) << 2) + ((e >> 9) << 4); }
+static inline size_t lds_padded_words(size_t n) { return n + ((n >> 5) << 2) + ((n >> 9) << 4) + 16; }
+
+template <typename W>
+__device__ __forceinline__ W csub(W x, W m) {  // x in [0, 2m) -> [0, m)
+    return min(x, static_cast<W>(x - m));
+}
+
+// x < 2^bits(W) -> [0, 2q) with muw = floor(2^bits(W) / q)
+template <typename W>
+__device__ __forceinline__ W fold_2q(W x, W q, W muw) {
+    return x - mulhi_w(x, muw) * q;
+}
+
+// ---- forward pass: stages [S_P, S_P + C), Cooley-Tukey, values grow by 2q per stage --------
+template <typename W, int C>
+__device__ __forceinline__ void ct_network_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p,
+                                                W q, W twoq) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const int half = 1 << (C - k - 1);
+        const uint32_t tb = (1u << (s_p + k)) + (bi << k);
+#pragma unroll
+        for (int u = 0; u < (1 << C); ++u) {
+            if (u & half) continue;
+            const TwPair<W> t = tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
+            const W V = v[u + half];
+            const W nT = V * t.w + mulhi_w(V, t.ws) * q;  // t.w holds -w
+            const W U = v[u];
+            v[u] = U - nT;
+            v[u + half] = U + twoq + nT;
+        }
+    }
+}
+
+// ---- inverse pass: Gentleman-Sande, input bound 2q, A-path bounds double per stage ----------
+// bound exponent of element u after the stages that used bits 0..j (bound = 2^e * q)
+__host__ __device__ constexpr int gs_exp_after(int u, int j) {
+    int e = 1;
+    for (int i = 0; i <= j; ++i) e = ((u >> i) & 1) ? 1 : e + 1;
+    return e;
+}
+
+template <typename W, int C, bool LAST>
+__device__ __forceinline__ void gs_network_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p,
+                                                W q, const LimbConst &lc) {
+#pragma unroll
+    for (int k = C - 1; k >= 0; --k) {
+        const int hb = C - k - 1;  // bit used by this stage
+        const int half = 1 << hb;
+        const uint32_t tb = (1u << (s_p + k)) + (bi << k);
+#pragma unroll
+        for (int u = 0; u < (1 << C); ++u) {
+            if (u & half) continue;
+            const int e_in = hb == 0 ? 1 : gs_exp_after(u, hb - 1);  // same for u and u+half
+            const W M = q << e_in;                                  // bound of Y
+            const W X = v[u], Y = v[u + half];
+            const W D = X + M - Y;
+            if (LAST && k == 0) {
+                // last stage of the whole transform: fold N^-1 into both outputs
+                const W A = X + Y;
+                v[u] = A * static_cast<W>(lc.n_inv) - mulhi_w(A, static_cast<W>(lc.n_inv_sh)) * q;
+                v[u + half] = D * static_cast<W>(lc.inv_last_w) - mulhi_w(D, static_cast<W>(lc.inv_last_w_sh)) * q;
+            } else {
+                const TwPair<W> t = tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
+                v[u] = X + Y;
+                v[u + half] = D * t.w - mulhi_w(D, t.ws) * q;  // [0, 2q)
+            }
+        }
+    }
+}
+
+// bring every element of a finished inverse pass back to [0, 2q)
+template <typename W, int C>
+__device__ __forceinline__ void gs_fold(W (&v)[1 << C], W q, W muw) {
+#pragma unroll
+    for (int u = 0; u < (1 << C); ++u) {
+        const int e = gs_exp_after(u, C - 1);
+        if (e == 2) v[u] = csub<W>(v[u], q + q);
+        else if (e > 2) v[u] = fold_2q<W>(v[u], q, muw);
+    }
+}
+
+template <typename W, int LOGN, int LOGR, bool INV>
+struct NttLdsCfg {
+    static constexpr uint32_t N = 1u << LOGN;
+    static constexpr uint32_t T = 1u << (LOGN - LOGR);
+    static constexpr int P = (LOGN + LOGR - 1) / LOGR;
+    static constexpr int CLAST = LOGN - (P - 1) * LOGR;
+};
+
+// strided first/last pass straight from/to HBM: element set {tid + T*u}
+// middle and contiguous passes on LDS with compile-time offsets.
+template <typename W, int LOGN, int LOGR, int S_P, int C>
+__device__ __forceinline__ void lds_set_addr(uint32_t tid, int g, uint32_t &bi, uint32_t &pbase) {
+    constexpr uint32_t B = 1u << (LOGN - S_P);
+    constexpr uint32_t S = B >> C;
+    constexpr int G = 1 << (LOGR - C);
+    const uint32_t sigma = tid * G + g;
+    bi = sigma / S;
+    const uint32_t r = sigma - bi * S;
+    pbase = lds_pad_c(bi * B + r);
+}
+
+template <int S, int u>
+struct LdsOff {
+    static constexpr uint32_t value = lds_pad_c(static_cast<uint32_t>(S) * u);
+};
+
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
+    ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+                        uint32_t L) {
+    typedef NttLdsCfg<W, LOGN, LOGR, false> Cfg;
+    constexpr uint32_t N = Cfg::N, T = Cfg::T;
+    constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
+    static_assert(P == 3, "three passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W *x = reinterpret_cast<W *>(smem);
+    const uint32_t tid = threadIdx.x;
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q), twoq = q + q;
+    const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
+    W *g = data + vec * N;
+
+    {   // pass 0: stages [0, LOGR), elements tid + T*u straight from HBM (coalesced per u)
+        W v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = g[tid + T * u];
+        ct_network_lazy<W, LOGR>(v, tw, 0, 0, q, twoq);
+        const uint32_t pb = lds_pad_c(tid);
+#pragma unroll
+        for (int u = 0; u < R; ++u) x[pb + lds_pad_c(T * u)] = v[u];
+    }
+    __syncthreads();
+    {   // pass 1: stages [LOGR, 2 LOGR)
+        constexpr uint32_t B = 1u << (LOGN - LOGR), S = B >> LOGR;
+        uint32_t bi, pb;
+        lds_set_addr<W, LOGN, LOGR, LOGR, LOGR>(tid, 0, bi, pb);
+        W v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
+        ct_network_lazy<W, LOGR>(v, tw, bi, LOGR, q, twoq);
+#pragma unroll
+        for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = v[u];
+    }
+    __syncthreads();
+    {   // pass 2: stages [2 LOGR, LOGN): R contiguous words per thread
+        constexpr int G = 1 << (LOGR - CLAST), E = 1 << CLAST;
+        const uint32_t pb0 = lds_pad_c(tid * R);
+        const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            W v[E];
+#pragma unroll
+            for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
+            ct_network_lazy<W, CLAST>(v, tw, tid * G + gi, 2 * LOGR, q, twoq);
+            // canonical form: values < (1 + 2 logN) q
+#pragma unroll
+            for (int u = 0; u < E; ++u) x[pb0 + gi * E + u] = csub<W>(fold_2q<W>(v[u], q, muw), q);
+        }
+    }
+    __syncthreads();
+    // LDS -> HBM, 16 bytes per lane
+    typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
+    constexpr int VN = 16 / sizeof(W);
+#pragma unroll
+    for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
+        const uint32_t i = tid + jj * T;
+        reinterpret_cast<V16 *>(g)[i] = *reinterpret_cast<const V16 *>(&x[lds_pad_c(i * VN)]);
+    }
+}
+
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
+    ntt_inv_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+                        uint32_t L) {
+    typedef NttLdsCfg<W, LOGN, LOGR, true> Cfg;
+    constexpr uint32_t N = Cfg::N, T = Cfg::T;
+    constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
+    static_assert(P == 3, "three passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W *x = reinterpret_cast<W *>(smem);
+    const uint32_t tid = threadIdx.x;
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q);
+    const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
+    const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
+    W *g = data + vec * N;
+
+    // HBM -> LDS, 16 bytes per lane
+    typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
+    constexpr int VN = 16 / sizeof(W);
+#pragma unroll
+    for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
+        const uint32_t i = tid + jj * T;
+        *reinterpret_cast<V16 *>(&x[lds_pad_c(i * VN)]) = reinterpret_cast<const V16 *>(g)[i];
+    }
+    __syncthreads();
+    {   // contiguous pass: stages [2 LOGR, LOGN) in GS order
+        constexpr int G = 1 << (LOGR - CLAST), E = 1 << CLAST;
+        const uint32_t pb0 = lds_pad_c(tid * R);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            W v[E];
+#pragma unroll
+            for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
+            gs_network_lazy<W, CLAST, false>(v, tw, tid * G + gi, 2 * LOGR, q, lc);
+            gs_fold<W, CLAST>(v, q, muw);
+#pragma unroll
+            for (int u = 0; u < E; ++u) x[pb0 + gi * E + u] = v[u];
+        }
+    }
+    __syncthreads();
+    {   // middle pass: stages [LOGR, 2 LOGR)
+        constexpr uint32_t B = 1u << (LOGN - LOGR), S = B >> LOGR;
+        uint32_t bi, pb;
+        lds_set_addr<W, LOGN, LOGR, LOGR, LOGR>(tid, 0, bi, pb);
+        W v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
+        gs_network_lazy<W, LOGR, false>(v, tw, bi, LOGR, q, lc);
+        gs_fold<W, LOGR>(v, q, muw);
+#pragma unroll
+        for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = v[u];
+    }
+    __syncthreads();
+    {   // strided pass: stages [0, LOGR), results straight to HBM (coalesced per u)
+        const uint32_t pb = lds_pad_c(tid);
+        W v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(T * u)];
+        gs_network_lazy<W, LOGR, true>(v, tw, 0, 0, q, lc);
+        // elements that did not go through the N^-1 Shoup product of the last stage carry
+        // A-path bounds from the earlier stages of this pass; those that did are < 2q
+#pragma unroll
+        for (int u = 0; u < R; ++u) g[tid + T * u] = csub<W>(v[u], q);
+    }
+}

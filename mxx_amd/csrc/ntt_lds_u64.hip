@@ -1,0 +1,12 @@
+// ntt_lds_u64.hip — instantiations of the lazy LDS NTT for 64-bit residue words.
+#include "ntt_lds.h"
+
+#include <atomic>
+#include <cstdlib>
+
+typedef uint64_t W;
+#include "ntt_lds_dispatch.inc"
+
+int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t L, bool inverse) {
+    return dispatch_ntt_lds(ctx, data, vectors, L, inverse);
+}

@@ -147,6 +147,18 @@ static int upload_tables(GpuContext *ctx, const std::vector<std::vector<uint64_t
     HIP_TRY(hipMemcpy(ctx->d_tw_fwd_sh, h_fs.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tw_inv, h_i.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tw_inv_sh, h_is.data(), bytes, hipMemcpyHostToDevice));
+    // interleaved {twiddle, companion} pairs for the lazy LDS kernels; forward twiddles negated
+    std::vector<W> h_pf(2 * L * N), h_pi(2 * L * N);
+    for (size_t i = 0; i < L * N; ++i) {
+        h_pf[2 * i] = static_cast<W>(0) - h_f[i];
+        h_pf[2 * i + 1] = h_fs[i];
+        h_pi[2 * i] = h_i[i];
+        h_pi[2 * i + 1] = h_is[i];
+    }
+    HIP_TRY(hipMalloc(&ctx->d_tw2_fwd, 2 * bytes));
+    HIP_TRY(hipMalloc(&ctx->d_tw2_inv, 2 * bytes));
+    HIP_TRY(hipMemcpy(ctx->d_tw2_fwd, h_pf.data(), 2 * bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tw2_inv, h_pi.data(), 2 * bytes, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -160,6 +172,8 @@ static void context_release(GpuContext *ctx) {
     if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);
     if (ctx->d_tw_inv_sh) (void)hipFree(ctx->d_tw_inv_sh);
     if (ctx->d_garner) (void)hipFree(ctx->d_garner);
+    if (ctx->d_tw2_fwd) (void)hipFree(ctx->d_tw2_fwd);
+    if (ctx->d_tw2_inv) (void)hipFree(ctx->d_tw2_inv);
     if (ctx->timer_start) (void)hipEventDestroy(ctx->timer_start);
     if (ctx->timer_stop) (void)hipEventDestroy(ctx->timer_stop);
     for (hipEvent_t ev : ctx->marks)
@@ -261,6 +275,9 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
         lc.mu64 = static_cast<uint64_t>((((u128h)1) << 64) / q);
         lc.n_inv = h_invmod_prime(N % q, q);
         lc.n_inv_sh = static_cast<uint64_t>(((u128h)lc.n_inv << (wide ? 64 : 32)) / q);
+        lc.mu32 = (((uint64_t)1) << 32) / q;
+        lc.inv_last_w = h_mulmod(inv[l][1 % N], lc.n_inv, q);
+        lc.inv_last_w_sh = static_cast<uint64_t>(((u128h)lc.inv_last_w << (wide ? 64 : 32)) / q);
         if (!wide) {
             u128h q2 = (u128h)(q - 1) * (q - 1);
             u128h terms = ((((u128h)1) << 64) - 1) / q2;
@@ -270,6 +287,7 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
         }
     }
     ctx->crt_bits = crt_bits;
+    ctx->lazy_ok = crt_bits + 7 <= (wide ? 64u : 32u);
 
     // Garner table: garner_inv[i*L + j] = (q_j)^-1 mod q_i for j < i
     // (mixed-radix CRT as the reference builds it, Runtime.cu:77-96)
