@@ -273,3 +273,85 @@ def random_matrix(seed: int, rows: int, cols: int, moduli, n: int) -> np.ndarray
     raw = splitmix64(seed, rows * cols * L * n).reshape(rows, cols, L, n)
     q = np.asarray(moduli, dtype=np.uint64).reshape(1, 1, L, 1)
     return raw % q
+
+
+# ----------------------------------------------------------------------------
+# seeded samplers (oracle_sampling.c)
+# ----------------------------------------------------------------------------
+def _seed_words(seed) -> np.ndarray:
+    if isinstance(seed, (bytes, bytearray)):
+        assert len(seed) == 32
+        return np.frombuffer(bytes(seed), dtype="<u8").astype(np.uint64).copy()
+    if hasattr(seed, "words"):
+        return np.array([int(w) for w in seed.words], dtype=np.uint64)
+    return np.ascontiguousarray(seed, dtype=np.uint64)
+
+
+def chacha20_block(state16) -> np.ndarray:
+    s = np.ascontiguousarray(state16, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    lib().orc_chacha20_block(s.ctypes.data_as(u32p), out.ctypes.data_as(u32p))
+    return out
+
+
+def rng_stream(seed, s0, s1, s2, tag, count) -> np.ndarray:
+    out = np.zeros(count, dtype=np.uint64)
+    lib().orc_rng_stream(_p(_seed_words(seed)), s0, s1, s2, tag, _p(out), count)
+    return out
+
+
+def karney_samples(seed, s0, mean, stddev, count) -> np.ndarray:
+    out = np.zeros(count, dtype=np.int64)
+    lib().orc_karney(_p(_seed_words(seed)), s0, float(mean), float(stddev), out.ctypes.data_as(_i64p), count)
+    return out
+
+
+DIST = {"uniform": 0, "gauss": 1, "bit": 2, "ternary": 3}
+
+
+def sample_distribution(rows, cols, moduli, n, dist: str, sigma, seed, full_ncol=None, col_offset=0) -> np.ndarray:
+    """COEFF residues (rows, cols, L, n) of the seeded sampler (before the NTT the ABI applies)."""
+    L = len(moduli)
+    out = np.zeros((rows, cols, L, n), dtype=np.uint64)
+    full = cols if full_ncol is None else full_ncol
+    lib().orc_sample_distribution(_p(out), rows, cols, full, col_offset, L, n, _p(_mod(moduli)), DIST[dist], float(sigma), _p(_seed_words(seed)))
+    return out
+
+
+def gauss_samp_gq(src_coeff: np.ndarray, moduli, base_bits: int, c: float, seed) -> np.ndarray:
+    src = np.ascontiguousarray(src_coeff, dtype=np.uint64)
+    rows, cols, L, n = src.shape
+    k = digits_per_tower(moduli, base_bits) * L
+    out = np.zeros((rows * k, cols, L, n), dtype=np.uint64)
+    lib().orc_gauss_samp_gq(_p(out), _p(src), rows, cols, L, n, _p(_mod(moduli)), base_bits, float(c), _p(_seed_words(seed)))
+    return out
+
+
+def p1_covariance(a, b, d, moduli, sigma, s, dgg_stddev):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    d = np.ascontiguousarray(d, dtype=np.uint64)
+    dd, _, L, n = a.shape
+    m = 2 * dd
+    sv = np.zeros((n, m), dtype=np.float64)
+    up = np.zeros((n, m, m), dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    lib().orc_p1_covariance(_p(a), _p(b), _p(d), dd, L, n, int(moduli[0]), float(sigma), float(s), float(dgg_stddev), sv.ctypes.data_as(dp), up.ctypes.data_as(dp))
+    return sv, up
+
+
+def sample_p1(tp2_coeff, moduli, sqrt_var, update, c_scale, seed) -> np.ndarray:
+    tp2 = np.ascontiguousarray(tp2_coeff, dtype=np.uint64)
+    m, cols, L, n = tp2.shape
+    out = np.zeros_like(tp2)
+    dp = C.POINTER(C.c_double)
+    sv = np.ascontiguousarray(sqrt_var, dtype=np.float64)
+    up = np.ascontiguousarray(update, dtype=np.float64)
+    lib().orc_sample_p1(_p(out), _p(tp2), m, cols, L, n, _p(_mod(moduli)), sv.ctypes.data_as(dp), up.ctypes.data_as(dp), float(c_scale), _p(_seed_words(seed)))
+    return out
+
+
+def centered(res: np.ndarray, q: int) -> np.ndarray:
+    r = res.astype(np.int64)
+    return np.where(r > q // 2, r - q, r)

@@ -1,0 +1,98 @@
+"""CPU-only: pins the sampler restatement (oracle/oracle_sampling.c)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+SEED = bytes(range(32))
+
+
+def test_chacha20_block_rfc8439_kat():
+    """RFC 8439 section 2.3.2 test vector."""
+    key = bytes(range(32))
+    nonce = bytes([0, 0, 0, 9, 0, 0, 0, 0x4A, 0, 0, 0, 0])
+    state = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]
+    state += [int.from_bytes(key[4 * i : 4 * i + 4], "little") for i in range(8)]
+    state += [1] + [int.from_bytes(nonce[4 * i : 4 * i + 4], "little") for i in range(3)]
+    out = O.chacha20_block(state)
+    assert [hex(int(x)) for x in out[:4]] == ["0xe4e7f110", "0x15593bd1", "0x1fdd0f50", "0xc47120a3"]
+    stream = b"".join(int(x).to_bytes(4, "little") for x in out)
+    assert stream[:16].hex() == "10f1e7e4d13b5915500fdd1fa32071c4"
+    assert stream[-8:].hex() == "cbd083e8a2503c4e"
+
+
+def test_rng_stream_is_keyed():
+    a = O.rng_stream(SEED, 1, 1, 1, 0x6F70656E66686531, 24)
+    b = O.rng_stream(SEED, 1, 1, 1, 0x6F70656E66686531, 24)
+    c = O.rng_stream(SEED, 2, 1, 1, 0x6F70656E66686531, 24)
+    d = O.rng_stream(SEED, 1, 1, 1, 0x6F70656E66686532, 24)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, d)
+    assert len(set(int(x) for x in a)) == 24  # block counter advances
+
+
+@pytest.mark.parametrize("sigma,mean", [(4.578, 0.0), (1.0, 0.3), (137.5, -20.25), (0.8, 0.0)])
+def test_karney_moments(sigma, mean):
+    x = O.karney_samples(SEED, 7, mean, sigma, 40000).astype(np.float64)
+    assert abs(x.mean() - mean) < 5 * sigma / np.sqrt(len(x)) + 0.02
+    assert abs(x.std() / max(sigma, (sigma**2 + 1 / 12) ** 0.5) - 1) < 0.05 or sigma < 1.0
+    assert np.abs(x - mean).max() < 6.5 * sigma + 1
+
+
+def test_distribution_sampler_properties_and_windows():
+    n, moduli = 64, O.gen_crt_basis(64, 3, 20)
+    full = O.sample_distribution(2, 5, moduli, n, "uniform", 0, SEED)
+    assert all(int(full[:, :, l].max()) < q for l, q in enumerate(moduli))
+    win = O.sample_distribution(2, 2, moduli, n, "uniform", 0, SEED, full_ncol=5, col_offset=2)
+    assert np.array_equal(win, full[:, 2:4])  # src/sampler/gpu.rs:323-361
+    for dist, lo, hi in [("bit", 0, 1), ("ternary", -1, 1)]:
+        s = O.sample_distribution(2, 3, moduli, n, dist, 0, SEED)
+        c = O.centered(s[:, :, 0], moduli[0])
+        assert c.min() >= lo and c.max() <= hi and len(np.unique(c)) == hi - lo + 1
+        for l, q in enumerate(moduli):  # the same integer in every limb
+            assert np.array_equal(O.centered(s[:, :, l], q), c)
+    g = O.sample_distribution(3, 3, moduli, n, "gauss", 3.2, SEED)
+    c = O.centered(g[:, :, 0], moduli[0])
+    assert np.abs(c).max() < 6 * 3.2 and abs(c.std() - 3.2) < 0.3  # |x| < 6 sigma (sampler/gpu.rs:363-400)
+
+
+@pytest.mark.parametrize("n,depth,bits,base", [(16, 2, 17, 1), (16, 2, 16, 4), (16, 3, 17, 5), (8, 2, 51, 17), (16, 2, 24, 12)])
+def test_g_sampler_relation_on_cpu(n, depth, bits, base):
+    """G * gauss_samp_gq(M) == M (gpu_dcrt_poly.rs:2381-2542)."""
+    moduli = O.gen_crt_basis(n, depth, bits)
+    M = O.random_matrix(9, 2, 2, moduli, n)
+    c = (2**base + 1) * 4.578
+    z = O.gauss_samp_gq(M, moduli, base, c, SEED)
+    G = O.gadget_matrix(2, moduli, n, base)
+    prod = O.matmul(G, O.matrix_ntt(z, moduli), moduli)
+    assert np.array_equal(O.matrix_ntt(prod, moduli, inverse=True), M)
+    zc = O.centered(z[:, :, 0], moduli[0])
+    assert np.abs(zc).max() < 8 * c  # short digits
+
+
+def test_p1_sampler_statistics():
+    """conditional sampling reproduces mean c_scale*tp2 and the requested covariance diagonal."""
+    n, moduli = 32, O.gen_crt_basis(32, 2, 24)
+    d = 1
+    rng = np.random.default_rng(1)
+
+    def small(shape, bound):
+        v = rng.integers(-bound, bound + 1, size=shape)
+        return np.stack([np.mod(v, q).astype(np.uint64) for q in moduli], axis=-2)
+
+    a = small((d, d, n), 50)
+    dm = small((d, d, n), 50)
+    b = small((d, d, n), 20)
+    sigma, s = 10.0, 400.0
+    sv, up = O.p1_covariance(a, b, dm, moduli, sigma, s, 4.0)
+    assert sv.shape == (n, 2) and np.all(sv > 0)
+    ac = O.centered(a[0, 0, 0], moduli[0])
+    assert np.allclose(sv[:, 1] ** 2, s * s - sigma * sigma * O.centered(dm[0, 0, 0], moduli[0]))
+    cols = 400
+    tp2 = small((2 * d, cols, n), 1000)
+    c_scale = -(sigma * sigma) / (s * s - sigma * sigma)
+    out = O.sample_p1(tp2, moduli, sv, up, c_scale, SEED)
+    z = O.centered(out[:, :, 0], moduli[0]).astype(np.float64)
+    mu = c_scale * O.centered(tp2[:, :, 0], moduli[0])
+    resid = z - mu
+    assert abs(resid.mean()) < 5 * s / np.sqrt(resid.size) * 2
+    assert abs(resid[1].std() / s - 1) < 0.1
