@@ -310,6 +310,48 @@ extern "C" int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
     ABI_GUARD_END
 }
 
+// S * G^-1(B) in one ABI call (extension; the Rust wrapper loops column chunks,
+// src/matrix/gpu_dcrt_poly.rs:1414-1493).  Column chunks bound the transient digit matrix
+// to ~1 GiB; each chunk is decompose -> NTT -> product straight into the output columns.
+extern "C" int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs,
+                                            uint32_t base_bits) {
+    ABI_GUARD_BEGIN
+    if (!out || !lhs || !rhs) return set_error("gpupoly_matrix_mul_decompose: null matrix");
+    if (out->ctx != lhs->ctx || out->ctx != rhs->ctx) return set_error("gpupoly_matrix_mul_decompose: context mismatch");
+    if (out->level != lhs->level || out->level != rhs->level)
+        return set_error("gpupoly_matrix_mul_decompose: level mismatch");
+    if (base_bits == 0) return set_error("gpupoly_matrix_mul_decompose: base_bits must be non-zero");
+    GpuContext *ctx = out->ctx;
+    const size_t L = matrix_limbs(out);
+    const size_t k = static_cast<size_t>((ctx->crt_bits + base_bits - 1) / base_bits) * L;
+    if (lhs->cols != rhs->rows * k || out->rows != lhs->rows || out->cols != rhs->cols)
+        return set_error("gpupoly_matrix_mul_decompose: shape mismatch");
+    if (lhs->format != GPU_POLY_FORMAT_EVAL) return set_error("gpupoly_matrix_mul_decompose requires Eval format");
+    out->format = GPU_POLY_FORMAT_EVAL;
+    if (matrix_polys(out) == 0) return 0;
+    const size_t poly_bytes = L * static_cast<size_t>(ctx->N) * ctx->word_bytes;
+    size_t chunk = std::max<size_t>(1, (size_t(1) << 30) / std::max<size_t>(1, rhs->rows * k * poly_bytes));
+    chunk = std::min(chunk, rhs->cols);
+    for (size_t c0 = 0; c0 < rhs->cols; c0 += chunk) {
+        const size_t cw = std::min(chunk, rhs->cols - c0);
+        GpuMatrix *slice = nullptr, *dec = nullptr, *prod = nullptr;
+        int rc = gpu_matrix_create(ctx, out->level, rhs->rows, cw, rhs->format, &slice);
+        if (!rc) rc = gpu_matrix_copy_block(slice, rhs, 0, 0, 0, c0, rhs->rows, cw);
+        if (!rc) rc = gpu_matrix_create(ctx, out->level, rhs->rows * k, cw, GPU_POLY_FORMAT_EVAL, &dec);
+        if (!rc) rc = gpu_matrix_decompose_base(slice, base_bits, dec);
+        if (!rc) rc = gpu_matrix_create(ctx, out->level, lhs->rows, cw, GPU_POLY_FORMAT_EVAL, &prod);
+        if (!rc) rc = gpu_matrix_mul(prod, lhs, dec);
+        if (!rc) rc = gpu_matrix_copy_block(out, prod, 0, c0, 0, 0, lhs->rows, cw);
+        gpu_matrix_destroy(slice);
+        gpu_matrix_destroy(dec);
+        gpu_matrix_destroy(prod);
+        if (rc) return rc;
+    }
+    out->format = GPU_POLY_FORMAT_EVAL;
+    return 0;
+    ABI_GUARD_END
+}
+
 extern "C" int gpu_matrix_equal(const GpuMatrix *lhs, const GpuMatrix *rhs, int *out_equal) {
     ABI_GUARD_BEGIN
     if (!out_equal) return set_error("gpu_matrix_equal: null out_equal");

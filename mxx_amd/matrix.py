@@ -28,6 +28,25 @@ def mul_decompose_column_chunk_width() -> int:
         return 1
 
 
+def _bincode_varint(v: int) -> bytes:
+    """bincode 2 `config::standard()` unsigned varint (u16/u32/u64/usize)."""
+    if v < 251:
+        return bytes([v])
+    if v < 1 << 16:
+        return bytes([251]) + v.to_bytes(2, "little")
+    if v < 1 << 32:
+        return bytes([252]) + v.to_bytes(4, "little")
+    return bytes([253]) + v.to_bytes(8, "little")
+
+
+def _bincode_read_varint(data: bytes, pos: int):
+    tag = data[pos]
+    if tag < 251:
+        return tag, pos + 1
+    width = {251: 2, 252: 4, 253: 8}[tag]
+    return int.from_bytes(data[pos + 1 : pos + 1 + width], "little"), pos + 1 + width
+
+
 class GpuP1CovarianceCache:
     def __init__(self, raw):
         self.raw = raw
@@ -193,6 +212,96 @@ class GpuDCRTPolyMatrix:
                 row.append([v % Q for v in vals])
             out.append(row)
         return out
+
+    # ------------------------------------------------------------------ compact wire format
+    def to_compact_bytes(self) -> bytes:
+        """`into_compact_bytes` (gpu_dcrt_poly.rs:956-1002): bincode(standard) tuple
+        (1u8, format u8, level u32, nrow usize, ncol usize, max_coeff_bits u16, bytes_per_coeff u16, payload)."""
+        return self.clone().into_compact_bytes()
+
+    def into_compact_bytes(self) -> bytes:
+        fmt = GPU_POLY_FORMAT_EVAL if self.is_ntt else GPU_POLY_FORMAT_COEFF
+        coeff_count = self.nrow * self.ncol * self.params.ring_dimension()
+        bits_upper = sum(q.bit_length() for q in self.params.moduli()[: self.level + 1])
+        cap = (coeff_count * bits_upper + 7) // 8
+        payload = (C.c_uint8 * max(cap, 1))()
+        max_bits, bpc, plen = C.c_uint16(0), C.c_uint16(0), C.c_size_t(0)
+        st = _ffi.lib().gpu_matrix_store_compact_bytes(
+            self.raw, payload, cap, C.byref(max_bits), C.byref(bpc), C.byref(plen)
+        )
+        check_status(st, "gpu_matrix_store_compact_bytes")
+        self.is_ntt = False  # the store converts in place (MatrixSerde.cu:1108-1118)
+        body = bytes(payload[: plen.value])
+        return b"".join(
+            [
+                bytes([1, fmt]),
+                _bincode_varint(self.level),
+                _bincode_varint(self.nrow),
+                _bincode_varint(self.ncol),
+                _bincode_varint(max_bits.value),
+                _bincode_varint(bpc.value),
+                _bincode_varint(len(body)),
+                body,
+            ]
+        )
+
+    @classmethod
+    def from_compact_bytes(cls, params, data: bytes) -> "GpuDCRTPolyMatrix":
+        """gpu_dcrt_poly.rs:1004-1044."""
+        version, fmt = data[0], data[1]
+        assert version == 1, f"Unsupported compact matrix version: {version}"
+        assert fmt in (GPU_POLY_FORMAT_COEFF, GPU_POLY_FORMAT_EVAL), f"Invalid compact matrix format tag: {fmt}"
+        pos = 2
+        level, pos = _bincode_read_varint(data, pos)
+        nrow, pos = _bincode_read_varint(data, pos)
+        ncol, pos = _bincode_read_varint(data, pos)
+        max_bits, pos = _bincode_read_varint(data, pos)
+        bpc, pos = _bincode_read_varint(data, pos)
+        plen, pos = _bincode_read_varint(data, pos)
+        payload = data[pos : pos + plen]
+        assert len(payload) == plen and pos + plen == len(data), "truncated compact bytes"
+        assert level < params.crt_depth(), f"invalid compact matrix level: {level}"
+        assert bpc == (max_bits + 7) // 8, "compact bytes_per_coeff mismatch"
+        out = cls(params, nrow, ncol, level, False)
+        buf = (C.c_uint8 * max(plen, 1)).from_buffer_copy(payload if plen else b"\0")
+        st = _ffi.lib().gpu_matrix_load_compact_bytes(out.raw, buf, plen, max_bits)
+        check_status(st, "gpu_matrix_load_compact_bytes")
+        out.is_ntt = False
+        if fmt == GPU_POLY_FORMAT_EVAL:
+            out.ntt_all_in_place()
+        return out
+
+    def to_cpu_staging_bytes(self) -> bytes:
+        """RNS snapshot framing (gpu_dcrt_poly.rs:1046-1061): (1u8, nrow, ncol, level, is_ntt, bytes_per_poly, bytes)."""
+        raw = self.to_rns().tobytes()
+        return b"".join(
+            [
+                bytes([1]),
+                _bincode_varint(self.nrow),
+                _bincode_varint(self.ncol),
+                _bincode_varint(self.level),
+                bytes([1 if self.is_ntt else 0]),
+                _bincode_varint(self._bytes_per_poly()),
+                _bincode_varint(len(raw)),
+                raw,
+            ]
+        )
+
+    @classmethod
+    def from_cpu_staging_bytes(cls, params, data: bytes) -> "GpuDCRTPolyMatrix":
+        assert data[0] == 1, "Unsupported GPU matrix RNS staging version"
+        pos = 1
+        nrow, pos = _bincode_read_varint(data, pos)
+        ncol, pos = _bincode_read_varint(data, pos)
+        level, pos = _bincode_read_varint(data, pos)
+        is_ntt = bool(data[pos])
+        pos += 1
+        bpp, pos = _bincode_read_varint(data, pos)
+        blen, pos = _bincode_read_varint(data, pos)
+        n = params.ring_dimension()
+        assert bpp == (level + 1) * n * 8 and blen == nrow * ncol * bpp
+        arr = np.frombuffer(data, dtype="<u8", count=blen // 8, offset=pos).reshape(nrow, ncol, level + 1, n)
+        return cls.from_rns(params, arr, is_ntt)
 
     # ------------------------------------------------------------------ domain
     def ntt_all_in_place(self) -> None:

@@ -58,6 +58,31 @@ class GpuDCRTTrapdoor:
             self._p1_cache = ((c, s, dgg_stddev), cache)
             return cache
 
+    def to_compact_bytes(self) -> bytes:
+        """R then E, each as u64-LE length + compact matrix bytes (gpu.rs:82-97)."""
+        out = b""
+        for m in (self.r, self.e):
+            b = m.to_compact_bytes()
+            out += len(b).to_bytes(8, "little") + b
+        return out
+
+    @classmethod
+    def from_compact_bytes(cls, params, data: bytes):
+        """gpu.rs:99-129; returns None on malformed input like the reference's Option."""
+        mats, off = [], 0
+        for _ in range(2):
+            if off + 8 > len(data):
+                return None
+            ln = int.from_bytes(data[off : off + 8], "little")
+            off += 8
+            if off + ln > len(data):
+                return None
+            mats.append(GpuDCRTPolyMatrix.from_compact_bytes(params, data[off : off + ln]))
+            off += ln
+        if off != len(data):
+            return None
+        return cls(mats[0], mats[1])
+
     def __eq__(self, other):
         return isinstance(other, GpuDCRTTrapdoor) and self.r == other.r and self.e == other.e
 

@@ -355,3 +355,34 @@ def sample_p1(tp2_coeff, moduli, sqrt_var, update, c_scale, seed) -> np.ndarray:
 def centered(res: np.ndarray, q: int) -> np.ndarray:
     r = res.astype(np.int64)
     return np.where(r > q // 2, r - q, r)
+
+
+def compact_payload(coeff_rns: np.ndarray, moduli):
+    """Compact wire payload of a COEFF matrix (python ints; small cases only).
+
+    Follows cuda/src/matrix/MatrixSerde.cu:280-456,1535-1627 of the reference: per
+    coefficient (poly-major) the centred representative of the CRT value, |x| in the low
+    w-1 bits and the sign in bit w-1, little-endian bit stream; w = 1 + max bit-length of
+    |x| (0 for all-zero).  Returns (payload bytes, max_coeff_bits, bytes_per_coeff)."""
+    rows, cols, L, n = coeff_rns.shape
+    moduli = [int(q) for q in moduli[:L]]
+    Q = 1
+    for q in moduli:
+        Q *= q
+    weights = []
+    for q in moduli:
+        Qi = Q // q
+        weights.append(Qi * pow(Qi, -1, q))
+    vals = []
+    for r in range(rows):
+        for c in range(cols):
+            for i in range(n):
+                x = sum(int(coeff_rns[r, c, l, i]) * weights[l] for l in range(L)) % Q
+                vals.append((Q - x, 1) if x > Q // 2 else (x, 0))
+    width = max((m.bit_length() for m, _ in vals), default=0)
+    width = width + 1 if width else 0
+    stream = 0
+    for idx, (m, s) in enumerate(vals):
+        stream |= (m | (s << (width - 1))) << (idx * width) if width else 0
+    nbytes = (len(vals) * width + 7) // 8
+    return stream.to_bytes(nbytes, "little"), width, (width + 7) // 8
