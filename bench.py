@@ -59,7 +59,7 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.torch = None
-        if n_gpus > 1:
+        if n_gpus > 1 or os.environ.get("MXX_BENCH_FORCE_DIST") == "1":  # the env rehearses the N>1 path on one GPU
             import torch
             import torch.distributed as dist
 
@@ -124,13 +124,16 @@ def upload_random(mx, params, rows, cols, seed, eval_format, chunk_polys=256):
 
 def main():
     args = parse_args()
+    # torch (N>1 only) must be imported BEFORE libgpupoly is loaded: the wheel bundles its own
+    # libamdhip64.so.7, and a process must hold exactly one HIP runtime; loaded in this order
+    # libgpupoly binds to the copy torch already mapped (same soname)
+    d = Dist(args.gpus)
     import mxx_amd as mx
     from mxx_amd import _ffi
 
-    d = Dist(args.gpus)
     if mx.detected_gpu_device_count() == 0:
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    device = d.local_rank if args.gpus > 1 else 0
+    device = d.local_rank if d.torch is not None else 0
     n = 16384
     wl = args.workload
     depth = {"m1": 4, "m2a": 15, "m2b": 8, "m3a": 10}[wl]
@@ -170,12 +173,26 @@ def main():
         out = mx.GpuDCRTPolyMatrix(params, r, c, L - 1, True)
         lib = _ffi.lib()
 
+        gather = None
+        if d.torch is not None:
+            # the one real exchange step of the sharded product: every rank owns a block of
+            # `c` output columns and all-gathers the blocks over xGMI (RCCL), zero-copy from
+            # the engine's HBM allocation
+            from mxx_amd.parallel import DeviceBuffer
+
+            src_t = DeviceBuffer(out).tensor(device)
+            full_t = d.torch.empty(d.dist.get_world_size() * src_t.numel(), dtype=src_t.dtype, device=src_t.device)
+            gather = (src_t, full_t)
+
         def step(i, mark):
             if mark:
                 ctx.timer_mark(2 * i)
             _ffi.check_status(lib.gpu_matrix_mul(out.raw, a.raw, b.raw), "gpu_matrix_mul")
             if mark:
                 ctx.timer_mark(2 * i + 1)
+            if gather is not None:
+                mx.gpu_device_sync()  # engine stream -> torch stream hand-off
+                d.dist.all_gather_into_tensor(gather[1], gather[0])
 
         units_per_step = r * k * c
         metric, unit = "dcrt_ring_ops_per_s", "ring-ops/s"
@@ -261,7 +278,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": workload_desc, "ring_dim": n, "limbs": L, "limb_bits": 24,
-                       "units_per_step_per_gpu": units_per_step, "sharding": "independent polys per rank, no collective"},
+                       "units_per_step_per_gpu": units_per_step,
+                       "sharding": ("column blocks per rank + RCCL all-gather of the product" if (wl in ("m2a", "m2b") and args.gpus > 1)
+                                    else "independent polys / target columns per rank, no collective")},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
@@ -273,7 +292,15 @@ def cpu_baseline(wl, n, moduli, budget_s):
     """The CPU restatement (oracle/, kind 'port') on this box's host cores, bounded sample."""
     from oracle import oracle as O
 
-    cores = O.lib().orc_max_threads()
+    # the box's CPU share, not the host's thread count (a 1-GPU box gets a slice of the host)
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    O.lib().orc_set_threads(cores)
     L = len(moduli)
     if wl == "m1":
         polys = 128
