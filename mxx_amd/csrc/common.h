@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <exception>
+#include <map>
+#include <unordered_map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -59,7 +61,11 @@ struct GpuContext {
     hipEvent_t timer_start = nullptr, timer_stop = nullptr;
     std::vector<hipEvent_t> marks;  // lazily created timing marks
     std::mutex mutex;
-    bool pool_ok = false;  // stream-ordered allocator usable
+    bool pool_ok = false;  // cache freed blocks (stream-ordered reuse)
+    std::mutex alloc_mutex;
+    std::multimap<size_t, void *> free_blocks;      // size -> block
+    std::unordered_map<void *, size_t> live_blocks;  // block -> size
+    size_t cached_bytes = 0, cache_limit = 0;
 };
 
 struct GpuMatrix {

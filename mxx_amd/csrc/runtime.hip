@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <iterator>
 #include <cstring>
 
 typedef unsigned __int128 u128h;
@@ -101,26 +102,72 @@ int ctx_activate(const GpuContext *ctx) {
     return 0;
 }
 
+// Stream-ordered caching allocator.  Every operation of a context is enqueued on its one
+// stream, so a block returned here can be handed out again immediately: whatever uses it
+// next is ordered behind whatever used it last.  Blocks come from plain hipMalloc (the
+// runtime's hipMallocAsync pool corrupted large D2D/D2H copies under rapid reuse on ROCm
+// 7.2 / gfx950 — tools/stress_prims.py — so it is not used); cached bytes are capped by
+// MXX_HIP_MEMPOOL_RELEASE_THRESHOLD_BYTES (the reference's
+// MXX_CUDA_MEMPOOL_RELEASE_THRESHOLD_BYTES is honoured too, Runtime.cu:337-361).
+static size_t round_block(size_t bytes) {
+    const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : 4096;
+    return (bytes + gran - 1) / gran * gran;
+}
+
+static void cache_trim(GpuContext *ctx, size_t limit) {
+    // caller holds ctx->alloc_mutex; hipFree synchronises, which is fine on this rare path
+    while (ctx->cached_bytes > limit && !ctx->free_blocks.empty()) {
+        auto it = std::prev(ctx->free_blocks.end());  // largest first
+        (void)hipFree(it->second);
+        ctx->cached_bytes -= it->first;
+        ctx->free_blocks.erase(it);
+    }
+}
+
 int ctx_alloc(GpuContext *ctx, size_t bytes, void **out) {
     *out = nullptr;
     if (bytes == 0) return 0;
-    if (ctx->pool_ok) {
-        hipError_t e = hipMallocAsync(out, bytes, ctx->stream);
-        if (e == hipSuccess) return 0;
-        (void)hipGetLastError();
+    const size_t want = round_block(bytes);
+    std::lock_guard<std::mutex> lk(ctx->alloc_mutex);
+    auto it = ctx->free_blocks.lower_bound(want);
+    if (it != ctx->free_blocks.end() && it->first <= want + want / 4) {
+        *out = it->second;
+        ctx->live_blocks[*out] = it->first;
+        ctx->cached_bytes -= it->first;
+        ctx->free_blocks.erase(it);
+        return 0;
     }
-    HIP_TRY(hipMalloc(out, bytes));
+    hipError_t e = hipMalloc(out, want);
+    if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+        (void)hipGetLastError();
+        cache_trim(ctx, 0);
+        e = hipMalloc(out, want);
+        if (e != hipSuccess) {
+            *out = nullptr;
+            return set_error(e, "hipMalloc");
+        }
+    }
+    ctx->live_blocks[*out] = want;
     return 0;
 }
 
 void ctx_free(GpuContext *ctx, void *ptr) {
     if (!ptr) return;
-    if (ctx->pool_ok) {
-        if (hipFreeAsync(ptr, ctx->stream) == hipSuccess) return;
-        (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(ctx->alloc_mutex);
+    auto it = ctx->live_blocks.find(ptr);
+    if (it == ctx->live_blocks.end()) {
+        (void)hipFree(ptr);
+        return;
     }
-    // hipFree synchronises the device: still correct for in-flight work
-    (void)hipFree(ptr);
+    const size_t size = it->second;
+    ctx->live_blocks.erase(it);
+    if (!ctx->pool_ok) {  // MXX_HIP_DISABLE_MEMPOOL=1: no caching
+        (void)hipFree(ptr);
+        return;
+    }
+    ctx->free_blocks.emplace(size, ptr);
+    ctx->cached_bytes += size;
+    cache_trim(ctx, ctx->cache_limit);
 }
 
 template <typename W>
@@ -166,6 +213,8 @@ static void context_release(GpuContext *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+    for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->d_limbs) (void)hipFree(ctx->d_limbs);
     if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
     if (ctx->d_tw_fwd_sh) (void)hipFree(ctx->d_tw_fwd_sh);
@@ -228,23 +277,12 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return set_error(e, "hipStreamCreate"); }
 
-    // stream-ordered pool: keep freed blocks cached (env mirrors the reference's
-    // MXX_CUDA_MEMPOOL_RELEASE_THRESHOLD_BYTES, Runtime.cu:337-361)
     {
-        int supported = 0;
-        if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, ctx->device) == hipSuccess &&
-            supported) {
-            hipMemPool_t pool;
-            if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess) {
-                uint64_t threshold = UINT64_MAX;
-                const char *env = std::getenv("MXX_HIP_MEMPOOL_RELEASE_THRESHOLD_BYTES");
-                if (!env) env = std::getenv("MXX_CUDA_MEMPOOL_RELEASE_THRESHOLD_BYTES");
-                if (env && *env) threshold = std::strtoull(env, nullptr, 10);
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
-                ctx->pool_ok = true;
-            }
-        }
-        (void)hipGetLastError();
+        ctx->pool_ok = true;
+        ctx->cache_limit = size_t(192) << 30;
+        const char *env = std::getenv("MXX_HIP_MEMPOOL_RELEASE_THRESHOLD_BYTES");
+        if (!env) env = std::getenv("MXX_CUDA_MEMPOOL_RELEASE_THRESHOLD_BYTES");
+        if (env && *env) ctx->cache_limit = std::strtoull(env, nullptr, 10);
         const char *nopool = std::getenv("MXX_HIP_DISABLE_MEMPOOL");
         if (nopool && *nopool == '1') ctx->pool_ok = false;
     }

@@ -19,7 +19,7 @@ static constexpr uint64_t kTagBit = 0x6f70656e66686533ull;
 static constexpr uint64_t kTagTernary = 0x6f70656e66686534ull;
 
 template <typename W>
-__global__ void sample_distribution_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
+__global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
                                            size_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L,
                                            uint32_t N, int dist, double sigma, GpuRngSeed seed) {
     const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -26,7 +26,7 @@ static constexpr int kGaussMaxDigits = 64;
 
 // ---- G-lattice sampler ------------------------------------------------------------------------
 template <typename W, int MAXD>
-__global__ void gauss_samp_gq_kernel(W *__restrict__ out, const W *__restrict__ src,
+__global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out, const W *__restrict__ src,
                                      const LimbConst *__restrict__ limbs, size_t src_polys, uint32_t src_cols,
                                      uint32_t L, uint32_t N, uint32_t dpt, uint32_t base_bits, double c, size_t k,
                                      GpuRngSeed seed) {
@@ -249,7 +249,7 @@ __global__ void p1_covariance_kernel(const W *__restrict__ a_mat, const W *__res
 
 // MAXM > 0: mean/sample vectors in registers; MAXM == 0: per-thread slices of a global workspace
 template <typename W, int MAXM>
-__global__ void p1_sample_kernel(W *__restrict__ out, const W *__restrict__ tp2,
+__global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, const W *__restrict__ tp2,
                                  const LimbConst *__restrict__ limbs, const double *__restrict__ sqrt_var_base,
                                  const double *__restrict__ update_base, uint32_t m, uint32_t cols, uint32_t L,
                                  uint32_t N, uint64_t q0, double c_scale, GpuRngSeed seed,

@@ -18,12 +18,12 @@ __global__ void rate_kernel(uint32_t *out, uint32_t seed) {
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int i = 0; i < UNROLL; ++i) {
-            if (OP == 0) a[i] = a[i] * b;                                   // v_mul_lo_u32
+            if (OP == 0) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));  // v_mul_lo_u32
             else if (OP == 1) a[i] = __umulhi(a[i], b);                     // v_mul_hi_u32
-            else if (OP == 2) w[i] = (uint64_t)(uint32_t)w[i] * b + w[i];    // v_mad_u64_u32
+            else if (OP == 2) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(b) : "vcc");  // v_mad_u64_u32
             else if (OP == 3) a[i] = __umul24(a[i], b);       // v_mul_u32_u24
             else if (OP == 4) a[i] = __umul24(a[i], b) + c;                  // v_mad_u32_u24
-            else if (OP == 5) a[i] = a[i] + b;                               // v_add_u32
+            else if (OP == 5) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));  // v_add_u32
             else if (OP == 6) a[i] = min(a[i], a[i] - b);                    // v_sub + v_min
             else if (OP == 7) d[i] = fma(d[i], 1.0000001, 0.5);              // v_fma_f64
             else if (OP == 8) a[i] = __builtin_amdgcn_alignbit(a[i], b, 24);  // v_alignbit_b32
