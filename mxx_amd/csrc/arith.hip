@@ -179,6 +179,141 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ---- LDS-tiled product for fat shapes (u32 words) -------------------------------------------
+// Workgroup = 64 consecutive evaluation slots (one per lane) x a 16x16 tile of C; its four
+// waves own 8x8 sub-tiles.  Per K-chunk of 4 the workgroup stages A[16 rows][4 k] and
+// B[4 k][16 cols] for its 64 slots in LDS (layout [entry][slot][k]: one 16-byte read per
+// entry gives a lane its 4 k-values, conflict-free), so every operand word is fetched from
+// L2/HBM once per workgroup instead of once per 8x8 register tile.  Double-buffered: the
+// next chunk's global loads are in flight while the current one is multiplied; one barrier
+// per chunk.  Blocks are numbered so that the tiles of one (limb, slot chunk) — which share
+// all their A and B panels — run on the same XCD's L2.
+static constexpr int kMmKC = 4;
+
+__global__ void __launch_bounds__(256, 2)
+    matmul_lds_kernel_u32(uint32_t *__restrict__ C, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
+                          const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols,
+                          uint32_t L, uint32_t N, uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks,
+                          uint32_t xcd_remap) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][2][16][64][kMmKC];  // [buf][A|B][entry][slot][k]
+    const uint32_t tiles = row_tiles * col_tiles;
+    uint32_t id = blockIdx.x, tile, group;
+    if (xcd_remap) {
+        const uint32_t xcd = id & 7u, j = id >> 3;
+        tile = j % tiles;
+        group = (j / tiles) * 8u + xcd;
+    } else {
+        tile = id % tiles;
+        group = id / tiles;
+    }
+    const uint32_t limb = group / slot_chunks, chunk = group - limb * slot_chunks;
+    const uint32_t rt = tile / col_tiles, ct = tile - rt * col_tiles;
+    const uint32_t r0 = rt * 16, c0 = ct * 16;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wr = wave >> 1, wc = wave & 1u;
+    const uint32_t slot = chunk * 64u + lane;
+    const LimbConst lc = limbs[limb];
+    const uint32_t q = static_cast<uint32_t>(lc.q);
+    const size_t polyw = static_cast<size_t>(L) * N;
+    const size_t base = static_cast<size_t>(limb) * N + slot;
+
+    // this wave stages A rows r0+4*wave.. and B cols c0+4*wave.. (4 each) for every k of a chunk
+    uint32_t ga[4][kMmKC], gb[4][kMmKC];
+    auto fetch = [&](uint32_t k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t rr = min(r0 + 4 * wave + e, rows - 1);
+            const uint32_t cc = min(c0 + 4 * wave + e, cols - 1);
+#pragma unroll
+            for (int kk = 0; kk < kMmKC; ++kk) {
+                const uint32_t k = k0 + kk;
+                const uint32_t kc = min(k, inner - 1);
+                const uint32_t av = A[(static_cast<size_t>(rr) * inner + kc) * polyw + base];
+                const uint32_t bv = B[(static_cast<size_t>(kc) * cols + cc) * polyw + base];
+                ga[e][kk] = k < inner ? av : 0u;
+                gb[e][kk] = k < inner ? bv : 0u;
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<uint4 *>(&lds[buf][0][4 * wave + e][lane][0]) = make_uint4(ga[e][0], ga[e][1], ga[e][2], ga[e][3]);
+            *reinterpret_cast<uint4 *>(&lds[buf][1][4 * wave + e][lane][0]) = make_uint4(gb[e][0], gb[e][1], gb[e][2], gb[e][3]);
+        }
+    };
+
+    uint64_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+
+    const uint32_t nchunks = (inner + kMmKC - 1) / kMmKC;
+    const uint32_t lazy = lc.lazy_terms;
+    uint32_t pending = 0;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) fetch((ch + 1) * kMmKC);
+        uint4 a4[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a4[i] = *reinterpret_cast<const uint4 *>(&lds[buf][0][wr * 8 + i][lane][0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint4 b4 = *reinterpret_cast<const uint4 *>(&lds[buf][1][wc * 8 + j][lane][0]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i][j] += static_cast<uint64_t>(a4[i].x) * b4.x;
+                acc[i][j] += static_cast<uint64_t>(a4[i].y) * b4.y;
+                acc[i][j] += static_cast<uint64_t>(a4[i].z) * b4.z;
+                acc[i][j] += static_cast<uint64_t>(a4[i].w) * b4.w;
+            }
+        }
+        pending += kMmKC;
+        if (pending + kMmKC > lazy) {
+            pending = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+        }
+        if (ch + 1 < nchunks) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = r0 + wr * 8 + i;
+        if (r >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t c = c0 + wc * 8 + j;
+            if (c >= cols) continue;
+            C[(static_cast<size_t>(r) * cols + c) * polyw + base] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+        }
+    }
+}
+
+static int launch_matmul_lds_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    GpuContext *ctx = out->ctx;
+    const uint32_t rows = static_cast<uint32_t>(lhs->rows), inner = static_cast<uint32_t>(lhs->cols),
+                   cols = static_cast<uint32_t>(rhs->cols);
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(out)), N = static_cast<uint32_t>(ctx->N);
+    const uint32_t row_tiles = (rows + 15) / 16, col_tiles = (cols + 15) / 16, slot_chunks = N / 64;
+    const uint64_t groups = static_cast<uint64_t>(L) * slot_chunks;
+    const uint64_t blocks = groups * row_tiles * col_tiles;
+    if (blocks > 0x7fffffffull) return set_error("gpu_matrix_mul: matrix too large");
+    const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
+    hipLaunchKernelGGL(matmul_lds_kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
+                       static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
+                       static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
+                       col_tiles, slot_chunks, remap);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <typename W, int TR, int TC, int SV>
 static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
     GpuContext *ctx = out->ctx;
@@ -208,6 +343,13 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
             return launch_matmul_cfg<uint64_t, 1, 4, 2>(out, lhs, rhs);
         }
         return launch_matmul_cfg<uint64_t, 1, 4, 1>(out, lhs, rhs);
+    }
+    {
+        // MXX_HIP_MATMUL_PATH = reg | lds forces a kernel family (tests cover both)
+        const char *force = std::getenv("MXX_HIP_MATMUL_PATH");
+        const bool lds_ok = N >= 64 && (N % 64) == 0;
+        const bool want_lds = force ? (force[0] == 'l') : (rows >= 8 && cols >= 8);
+        if (lds_ok && want_lds) return launch_matmul_lds_u32(out, lhs, rhs);
     }
     if (N >= 4) {
         if (rows >= 4) return launch_matmul_cfg<uint32_t, 4, 8, 1>(out, lhs, rhs);
@@ -257,7 +399,10 @@ extern "C" int gpu_matrix_add(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
         return 1;
     int rc = launch_elementwise<OP_ADD, false>(out, lhs, rhs);
     if (rc) return rc;
-    out->format = GPU_POLY_FORMAT_EVAL;  // quirk kept: MatrixArith.cu:2694
+    // The reference tags the result EVAL unconditionally (MatrixArith.cu:2694), which makes a later
+    // gpu_matrix_ntt_all on a COEFF+COEFF sum a silent no-op.  The op is format-agnostic, so the
+    // result keeps the operands' format; identical for EVAL operands, the only case that works there.
+    out->format = rhs->format;
     return 0;
     ABI_GUARD_END
 }
@@ -268,7 +413,7 @@ extern "C" int gpu_matrix_sub(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
         return 1;
     int rc = launch_elementwise<OP_SUB, false>(out, lhs, rhs);
     if (rc) return rc;
-    out->format = GPU_POLY_FORMAT_EVAL;
+    out->format = rhs->format;  // see gpu_matrix_add
     return 0;
     ABI_GUARD_END
 }

@@ -143,6 +143,38 @@ def test_matmul_vs_oracle(gpu, oracle, shape, n, depth, bits, base):
     assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
 
 
+@pytest.mark.parametrize("path", ["reg", "lds"])
+@pytest.mark.parametrize("shape", [(8, 8, 8), (9, 5, 17), (16, 16, 16), (20, 7, 33), (1, 6, 40), (33, 3, 9)])
+def test_matmul_kernel_families(gpu, oracle, path, shape):
+    """register-tiled and LDS-tiled products agree with the oracle on ragged shapes (n >= 64)."""
+    r, k, c = shape
+    n = 128
+    p = make_params(gpu, oracle, n, 2, 24, 12)
+    moduli = p.moduli()
+    a = rand_matrix(oracle, 25, r, k, moduli, n)
+    b = rand_matrix(oracle, 26, k, c, moduli, n)
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    os.environ["MXX_HIP_MATMUL_PATH"] = path
+    try:
+        assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+    finally:
+        del os.environ["MXX_HIP_MATMUL_PATH"]
+
+
+def test_matmul_lds_lazy_window_31bit(gpu, oracle):
+    """LDS kernel with 31-bit primes: the 64-bit accumulators must be folded every chunk."""
+    n = 64
+    moduli = oracle.gen_crt_basis(n, 2, 31)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 8)
+    top = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1)
+    a = np.broadcast_to(top, (9, 37, len(moduli), n)).copy()
+    b = np.broadcast_to(top, (37, 10, len(moduli), n)).copy()
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+
+
 def test_matmul_worst_case_accumulation(gpu, oracle):
     """all residues = q-1, inner dimension past the lazy-accumulation window of 31-bit primes."""
     n = 16
