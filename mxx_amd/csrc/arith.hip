@@ -209,7 +209,9 @@ __global__ void __launch_bounds__(256, 2)
     const uint32_t limb = group / slot_chunks, chunk = group - limb * slot_chunks;
     const uint32_t rt = tile / col_tiles, ct = tile - rt * col_tiles;
     const uint32_t r0 = rt * 16, c0 = ct * 16;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the wave index is made an SGPR so that every operand address below is scalar base + lane
+    // offset (address arithmetic on the scalar unit, global_load saddr form)
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wr = wave >> 1, wc = wave & 1u;
     const uint32_t slot = chunk * 64u + lane;
     const LimbConst lc = limbs[limb];
@@ -219,19 +221,39 @@ __global__ void __launch_bounds__(256, 2)
 
     // this wave stages A rows r0+4*wave.. and B cols c0+4*wave.. (4 each) for every k of a chunk
     uint32_t ga[4][kMmKC], gb[4][kMmKC];
+    // scalar row/column base pointers, advanced by whole chunks: no multiplies in the loop
+    const uint32_t *pa[4], *pb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t rr = min(r0 + 4 * wave + e, rows - 1);
+        const uint32_t cc = min(c0 + 4 * wave + e, cols - 1);
+        pa[e] = A + static_cast<size_t>(rr) * inner * polyw + static_cast<size_t>(limb) * N + chunk * 64u;
+        pb[e] = B + static_cast<size_t>(cc) * polyw + static_cast<size_t>(limb) * N + chunk * 64u;
+    }
+    const size_t strideA = polyw, strideB = static_cast<size_t>(cols) * polyw;
     auto fetch = [&](uint32_t k0) {
+        if (k0 + kMmKC <= inner) {  // full chunk (wave-uniform branch)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t rr = min(r0 + 4 * wave + e, rows - 1);
-            const uint32_t cc = min(c0 + 4 * wave + e, cols - 1);
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int kk = 0; kk < kMmKC; ++kk) {
-                const uint32_t k = k0 + kk;
-                const uint32_t kc = min(k, inner - 1);
-                const uint32_t av = A[(static_cast<size_t>(rr) * inner + kc) * polyw + base];
-                const uint32_t bv = B[(static_cast<size_t>(kc) * cols + cc) * polyw + base];
-                ga[e][kk] = k < inner ? av : 0u;
-                gb[e][kk] = k < inner ? bv : 0u;
+                for (int kk = 0; kk < kMmKC; ++kk) {
+                    ga[e][kk] = pa[e][kk * strideA + lane];
+                    gb[e][kk] = pb[e][kk * strideB + lane];
+                }
+                pa[e] += kMmKC * strideA;
+                pb[e] += kMmKC * strideB;
+            }
+        } else {  // ragged tail: clamp the address, zero the value
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int kk = 0; kk < kMmKC; ++kk) {
+                    const bool live = k0 + kk < inner;
+                    const uint32_t av = pa[e][(live ? kk : 0) * strideA + lane];
+                    const uint32_t bv = pb[e][(live ? kk : 0) * strideB + lane];
+                    ga[e][kk] = live ? av : 0u;
+                    gb[e][kk] = live ? bv : 0u;
+                }
             }
         }
     };
@@ -264,13 +286,16 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint4 b4 = *reinterpret_cast<const uint4 *>(&lds[buf][1][wc * 8 + j][lane][0]);
+            // k in the middle, rows innermost: successive v_mad_u64_u32 hit 8 different accumulators,
+            // so the 64-bit multiply-add latency is covered without relying on the second wave
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[i][j] += static_cast<uint64_t>(a4[i].x) * b4.x;
-                acc[i][j] += static_cast<uint64_t>(a4[i].y) * b4.y;
-                acc[i][j] += static_cast<uint64_t>(a4[i].z) * b4.z;
-                acc[i][j] += static_cast<uint64_t>(a4[i].w) * b4.w;
-            }
+            for (int i = 0; i < 8; ++i) acc[i][j] += static_cast<uint64_t>(a4[i].x) * b4.x;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][j] += static_cast<uint64_t>(a4[i].y) * b4.y;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][j] += static_cast<uint64_t>(a4[i].z) * b4.z;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][j] += static_cast<uint64_t>(a4[i].w) * b4.w;
         }
         pending += kMmKC;
         if (pending + kMmKC > lazy) {
