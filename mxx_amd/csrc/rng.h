@@ -11,6 +11,16 @@
 // iteration caps (cuda/src/matrix/MatrixSampling.cu:30-147): only IEEE double
 // compare / add / mul / div / ceil are involved, so the CPU oracle reproduces the
 // stream bit for bit (both sides are built with -ffp-contract=off).
+//
+// Wave64 shape of the sampler.  A rejection sampler written as nested data-dependent
+// loops makes a wave pay the product of the per-level maxima over its 64 lanes, and a
+// ChaCha block refill inside such loops is executed once per straggling lane.  Here
+//   * every lane owns a 16-word ring of keystream in LDS; blocks are generated only at
+//     explicit, wave-convergent checkpoints (rng_fill), one per 8 draws at most;
+//   * Karney's algorithm is a flat state machine that consumes exactly one keystream
+//     word per step, so all lanes of a wave sit at the same program point and a wave
+//     pays max-over-lanes of the TOTAL draw count once.
+// The sequence of draws and decisions per lane is unchanged (bit-identical samples).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -18,9 +28,15 @@
 
 struct ChaChaRng {
     uint32_t state[16];
-    uint32_t block[16];
-    uint32_t pos;  // next u64 word inside block, 8 = exhausted
+    uint64_t *ring;    // this lane's ring: element s lives at ring[s * ring_stride]
+    uint32_t ring_stride;
+    uint32_t head;     // words consumed
+    uint32_t tail;     // words generated
 };
+
+// LDS bytes a block of `threads` lanes needs for its rings
+#define RNG_RING_WORDS 16
+#define RNG_LDS_BYTES(threads) ((threads) * RNG_RING_WORDS * sizeof(uint64_t))
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
@@ -44,8 +60,9 @@ __device__ __forceinline__ void chacha_rounds(uint32_t (&x)[16]) {
     }
 }
 
-__device__ __forceinline__ void rng_init(ChaChaRng &rng, const GpuRngSeed &seed, uint64_t stream0, uint64_t stream1,
-                                         uint64_t stream2, uint64_t domain_tag) {
+// ring_base: the block's LDS array of blockDim.x * 16 u64; call from every lane
+__device__ __forceinline__ void rng_init(ChaChaRng &rng, uint64_t *ring_base, const GpuRngSeed &seed, uint64_t stream0,
+                                         uint64_t stream1, uint64_t stream2, uint64_t domain_tag) {
     uint32_t x[16];
     x[0] = 0x61707865u; x[1] = 0x3320646eu; x[2] = 0x79622d32u; x[3] = 0x6b206574u;
 #pragma unroll
@@ -65,120 +82,193 @@ __device__ __forceinline__ void rng_init(ChaChaRng &rng, const GpuRngSeed &seed,
     rng.state[13] = static_cast<uint32_t>(stream0 >> 32);
     rng.state[14] = static_cast<uint32_t>(stream1);
     rng.state[15] = static_cast<uint32_t>(stream1 >> 32);
-    rng.pos = 8;
+    rng.ring = ring_base + threadIdx.x;
+    rng.ring_stride = blockDim.x;
+    rng.head = 0;
+    rng.tail = 0;
 }
 
-__device__ __forceinline__ uint64_t rng_next_u64(ChaChaRng &rng) {
-    if (rng.pos >= 8) {
+// Checkpoint: guarantees >= 8 words are available.  Call at wave-convergent points, at least
+// once per 8 draws.
+__device__ __forceinline__ void rng_fill(ChaChaRng &rng) {
+    if (rng.tail - rng.head < 8) {
         uint32_t x[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) x[i] = rng.state[i];
         chacha_rounds(x);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rng.block[i] = x[i] + rng.state[i];
-        if (++rng.state[12] == 0) ++rng.state[13];
-        rng.pos = 0;
-    }
-    // dynamic indexing of a register array would spill: select with a static unroll
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (static_cast<uint32_t>(i) == rng.pos) {
-            lo = rng.block[2 * i];
-            hi = rng.block[2 * i + 1];
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t lo = x[2 * i] + rng.state[2 * i], hi = x[2 * i + 1] + rng.state[2 * i + 1];
+            rng.ring[((rng.tail + i) & (RNG_RING_WORDS - 1)) * rng.ring_stride] =
+                static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
         }
+        if (++rng.state[12] == 0) ++rng.state[13];
+        rng.tail += 8;
     }
-    ++rng.pos;
-    return static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
 }
 
-// uniform double in (0,1) from the top 53 bits
-__device__ __forceinline__ double rng_uniform_open01(ChaChaRng &rng) {
+__device__ __forceinline__ uint64_t rng_next_u64(ChaChaRng &rng) {
+    const uint64_t v = rng.ring[(rng.head & (RNG_RING_WORDS - 1)) * rng.ring_stride];
+    ++rng.head;
+    return v;
+}
+
+__device__ __forceinline__ double u64_to_open01(uint64_t w) {
     const double scale = 1.0 / 9007199254740992.0;  // 2^-53
-    double u = static_cast<double>(rng_next_u64(rng) >> 11) * scale;
+    double u = static_cast<double>(w >> 11) * scale;
     if (u <= 0.0) u = scale;
     else if (u >= 1.0) u = 1.0 - scale;
     return u;
 }
 
+// needs 2 words
 __device__ __forceinline__ double rng_standard_normal(ChaChaRng &rng) {
     const double two_pi = 6.283185307179586476925286766559;
-    double u1 = rng_uniform_open01(rng);
-    double u2 = rng_uniform_open01(rng);
+    double u1 = u64_to_open01(rng_next_u64(rng));
+    double u2 = u64_to_open01(rng_next_u64(rng));
     return sqrt(-2.0 * log(u1)) * cos(two_pi * u2);
 }
 
 __device__ __forceinline__ uint64_t rng_uniform_mod(ChaChaRng &rng, uint64_t q) {
     const uint64_t max = ~0ull;
     const uint64_t threshold = max - (max % q);
-    for (;;) {
+    for (uint32_t step = 0;; ++step) {
+        if ((step & 7) == 0) rng_fill(rng);
         uint64_t x = rng_next_u64(rng);
         if (x < threshold) return x % q;
     }
 }
 
-// ---- Karney's exact discrete Gaussian (algorithm D of arXiv:1303.6257) -----------------
-// H: true with probability exp(-1/2)
-__device__ __forceinline__ bool karney_h(ChaChaRng &rng) {
-    double a = rng_uniform_open01(rng);
-    if (!(a < 0.5)) return true;
-    for (;;) {
-        double b = rng_uniform_open01(rng);
-        if (!(b < a)) return false;
-        a = rng_uniform_open01(rng);
-        if (!(a < b)) return true;
-    }
-}
-
-__device__ __forceinline__ int32_t karney_g(ChaChaRng &rng) {
-    int32_t n = 0;
-    while (karney_h(rng)) {
-        ++n;
-        if (n > 1024) break;
-    }
-    return n;
-}
-
-__device__ __forceinline__ bool karney_p(ChaChaRng &rng, int32_t n) {
-    while (n-- && karney_h(rng)) {
-    }
-    return n < 0;
-}
-
-__device__ __forceinline__ bool karney_b(ChaChaRng &rng, int32_t k, double x) {
-    double y = x;
-    int32_t n = 0;
-    const double m = static_cast<double>(2 * k + 2);
-    for (;; ++n) {
-        double z = rng_uniform_open01(rng);
-        if (!(z < y)) break;
-        double r = rng_uniform_open01(rng);
-        if (!(r < (2.0 * static_cast<double>(k) + x) / m)) break;
-        y = z;
-        if (n > 4096) break;
-    }
-    return (n % 2) == 0;
-}
-
+// ---- Karney's exact discrete Gaussian (algorithm D of arXiv:1303.6257) as a state machine --
+// One keystream word per step.  Sequential form it reproduces, draw for draw:
+//   trial: k = G();  if !P(k(k-1)) retry;  s = bit;  j = word % ceil(sigma);  x = ...;
+//          if x out of range retry;  (k+1) times B(k,x) must hold, else retry;  return s(i0+j)
+//   H (prob e^-1/2): a=U; if !(a<1/2) true; loop { b=U; if !(b<a) false; a=U; if !(a<b) true }
+//   G: count consecutive H successes (cap 1024);  P(n): n consecutive H successes
+//   B(k,x): y=x,n=0; loop { z=U; if !(z<y) stop; r=U; if !(r<(2k+x)/(2k+2)) stop; y=z; if n>4096 stop; ++n }
+//           result = n even
 static __device__ int64_t sample_integer_karney(ChaChaRng &rng, double mean, double stddev) {
     if (!(stddev > 0.0) || !isfinite(mean) || !isfinite(stddev)) return static_cast<int64_t>(llround(mean));
     const int64_t ceil_std = static_cast<int64_t>(ceil(stddev));
     if (ceil_std <= 0) return static_cast<int64_t>(llround(mean));
-    for (int iter = 0; iter < (1 << 16); ++iter) {
-        int32_t k = karney_g(rng);
-        if (!karney_p(rng, k * (k - 1))) continue;
-        int64_t s = (rng_next_u64(rng) & 1ull) ? 1 : -1;
-        double di0 = stddev * static_cast<double>(k) + static_cast<double>(s) * mean;
-        int64_t i0 = static_cast<int64_t>(ceil(di0));
-        double x0 = (static_cast<double>(i0) - di0) / stddev;
-        int64_t j = static_cast<int64_t>(rng_next_u64(rng) % static_cast<uint64_t>(ceil_std));
-        double x = x0 + static_cast<double>(j) / stddev;
-        if (!(x < 1.0) || (x == 0.0 && s < 0 && k == 0)) continue;
-        int32_t h = k + 1;
-        while (h-- > 0 && karney_b(rng, k, x)) {
+
+    enum { ST_H0 = 0, ST_H1, ST_H2, ST_SIGN, ST_J, ST_B0, ST_B1 };
+    int st = ST_H0;
+    bool in_p = false;       // H outcomes feed P (true) or G (false)
+    int32_t k = 0;           // G's count
+    int32_t p_left = 0;      // H successes P still needs
+    int32_t b_left = 0;      // B successes still needed
+    int32_t bn = 0;          // B's step parity counter
+    double ha = 0.0, hb = 0.0, x = 0.0, x0 = 0.0, y = 0.0, zz = 0.0, bthr = 0.0;
+    int64_t s = 1, i0 = 0, j = 0, result = 0;
+    int iter = 0;
+    bool done = false, fallback = false;
+
+    for (uint32_t step = 0; !done; ++step) {
+        if ((step & 7) == 0) rng_fill(rng);
+        const uint64_t w = rng_next_u64(rng);
+        const double u = u64_to_open01(w);
+        int hres = -1;      // outcome of H finished this step
+        int bres = -1;      // outcome of B finished this step
+        bool restart = false;
+        switch (st) {
+            case ST_H0:
+                ha = u;
+                if (!(ha < 0.5)) hres = 1; else st = ST_H1;
+                break;
+            case ST_H1:
+                hb = u;
+                if (!(hb < ha)) hres = 0; else st = ST_H2;
+                break;
+            case ST_H2:
+                ha = u;
+                if (!(ha < hb)) hres = 1; else st = ST_H1;
+                break;
+            case ST_SIGN: {
+                s = (w & 1ull) ? 1 : -1;
+                const double di0 = stddev * static_cast<double>(k) + static_cast<double>(s) * mean;
+                i0 = static_cast<int64_t>(ceil(di0));
+                x0 = (static_cast<double>(i0) - di0) / stddev;
+                st = ST_J;
+                break;
+            }
+            case ST_J:
+                j = static_cast<int64_t>(w % static_cast<uint64_t>(ceil_std));
+                x = x0 + static_cast<double>(j) / stddev;
+                if (!(x < 1.0) || (x == 0.0 && s < 0 && k == 0)) {
+                    restart = true;
+                } else {
+                    b_left = k + 1;
+                    bthr = (2.0 * static_cast<double>(k) + x) / static_cast<double>(2 * k + 2);
+                    y = x;
+                    bn = 0;
+                    st = ST_B0;
+                }
+                break;
+            case ST_B0:
+                zz = u;
+                if (!(zz < y)) bres = (bn % 2) == 0; else st = ST_B1;
+                break;
+            default:  // ST_B1
+                if (!(u < bthr)) {
+                    bres = (bn % 2) == 0;
+                } else {
+                    y = zz;
+                    if (bn > 4096) bres = (bn % 2) == 0;
+                    else { ++bn; st = ST_B0; }
+                }
+                break;
         }
-        if (h >= 0) continue;
-        return s * (i0 + j);
+        if (hres >= 0) {
+            if (!in_p) {  // G: count successes
+                bool g_done = hres == 0;
+                if (hres == 1) {
+                    ++k;
+                    if (k > 1024) g_done = true;
+                }
+                if (g_done) {
+                    p_left = k * (k - 1);
+                    if (p_left == 0) st = ST_SIGN;
+                    else { in_p = true; st = ST_H0; }
+                } else {
+                    st = ST_H0;
+                }
+            } else {  // P: needs p_left successes
+                if (hres == 1) {
+                    if (--p_left == 0) st = ST_SIGN; else st = ST_H0;
+                } else {
+                    restart = true;
+                }
+            }
+        }
+        if (bres >= 0) {
+            if (bres == 1) {
+                if (--b_left == 0) {
+                    result = s * (i0 + j);
+                    done = true;
+                } else {
+                    y = x;
+                    bn = 0;
+                    st = ST_B0;
+                }
+            } else {
+                restart = true;
+            }
+        }
+        if (restart) {
+            if (++iter >= (1 << 16)) {
+                fallback = true;
+                done = true;
+            } else {
+                k = 0;
+                in_p = false;
+                st = ST_H0;
+            }
+        }
     }
-    return static_cast<int64_t>(llround(mean + stddev * rng_standard_normal(rng)));
+    if (fallback) {
+        rng_fill(rng);
+        result = static_cast<int64_t>(llround(mean + stddev * rng_standard_normal(rng)));
+    }
+    return result;
 }

@@ -22,6 +22,7 @@ template <typename W>
 __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
                                            size_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L,
                                            uint32_t N, int dist, double sigma, GpuRngSeed seed) {
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
     const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= polys * N) return;
     const size_t p = idx / N;
@@ -32,20 +33,22 @@ __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict_
     ChaChaRng rng;
     if (dist == GPU_MATRIX_DIST_UNIFORM) {
         for (uint32_t l = 0; l < L; ++l) {
-            rng_init(rng, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, static_cast<uint64_t>(l) + 1, kTagUniform);
+            rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, static_cast<uint64_t>(l) + 1, kTagUniform);
             dst[static_cast<size_t>(l) * N] = static_cast<W>(rng_uniform_mod(rng, limbs[l].q));
         }
         return;
     }
     int64_t z;
     if (dist == GPU_MATRIX_DIST_GAUSS) {
-        rng_init(rng, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagGauss);
+        rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagGauss);
         z = sample_integer_karney(rng, 0.0, sigma);
     } else if (dist == GPU_MATRIX_DIST_BIT) {
-        rng_init(rng, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagBit);
+        rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagBit);
+        rng_fill(rng);
         z = static_cast<int64_t>(rng_next_u64(rng) & 1ull);
     } else {
-        rng_init(rng, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagTernary);
+        rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagTernary);
+        rng_fill(rng);
         const uint64_t pick = rng_next_u64(rng) % 3ull;
         z = pick == 0 ? 0 : (pick == 1 ? 1 : -1);
     }

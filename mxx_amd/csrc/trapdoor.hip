@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out,
                                      const LimbConst *__restrict__ limbs, size_t src_polys, uint32_t src_cols,
                                      uint32_t L, uint32_t N, uint32_t dpt, uint32_t base_bits, double c, size_t k,
                                      GpuRngSeed seed) {
+    __shared__ uint64_t ring[128 * RNG_RING_WORDS];
     const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t total = src_polys * L * N;
     if (idx >= total) return;
@@ -63,10 +64,13 @@ __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out,
         }
     }
     ChaChaRng rng;
-    rng_init(rng, seed, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1, static_cast<uint64_t>(i) + 1,
-             kTagGadget);
+    rng_init(rng, ring, seed, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1,
+             static_cast<uint64_t>(i) + 1, kTagGadget);
 #pragma unroll
-    for (int d = 0; d < MAXD; ++d) zf[d] = d < (int)dpt ? sigma * rng_standard_normal(rng) : 0.0;
+    for (int d = 0; d < MAXD; ++d) {
+        if ((d & 3) == 0) rng_fill(rng);  // 4 normals = 8 words per checkpoint
+        zf[d] = d < (int)dpt ? sigma * rng_standard_normal(rng) : 0.0;
+    }
 
     // perturbation p = L-factor applied to zf; l_d, h_d are the Cholesky entries of the
     // basis Gram matrix (Genise-Micciancio, alg. 3), folded into the running sums here
@@ -254,6 +258,7 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
                                  const double *__restrict__ update_base, uint32_t m, uint32_t cols, uint32_t L,
                                  uint32_t N, uint64_t q0, double c_scale, GpuRngSeed seed,
                                  double *__restrict__ mean_ws) {
+    __shared__ uint64_t ring[128 * RNG_RING_WORDS];
     const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= static_cast<size_t>(cols) * N) return;
     const uint32_t col = static_cast<uint32_t>(idx / N);
@@ -261,7 +266,7 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
     const double *sqrt_var = sqrt_var_base + static_cast<size_t>(i) * m;
     const double *upd = update_base + static_cast<size_t>(i) * m * m;
     ChaChaRng rng;
-    rng_init(rng, seed, static_cast<uint64_t>(col) + 1, static_cast<uint64_t>(i) + 1, 0, kTagP1);
+    rng_init(rng, ring, seed, static_cast<uint64_t>(col) + 1, static_cast<uint64_t>(i) + 1, 0, kTagP1);
 
     if constexpr (MAXM > 0) {
         double mean[MAXM];
