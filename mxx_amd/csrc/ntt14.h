@@ -1,0 +1,172 @@
+// ntt14.h — 2^14-point negacyclic NTT / INTT, "grouped" layout: 4 workgroups per CU.
+//
+// Why: with the whole 64 KB vector in LDS (ntt_lds.h) only two workgroups fit a CU; each one
+// alternates a memory phase (64 KB in, 64 KB out at the CU's HBM share) with a VALU phase of
+// about the same length, and two such customers keep two balanced servers ~2/3 busy
+// (measured: 148 us with 80 us of memory skeleton and ~93 us of VALU).  Four customers give
+// ~4/5.  The LDS footprint is cut to 18 KB per buffer by finishing stages 0..4 in registers
+// first: after them the vector is 32 independent 512-point sub-transforms ("blocks"), and
+// thread t holds element t of every block.  Blocks are then processed 8 at a time (one per
+// wave): one transposing LDS write + ONE workgroup barrier per group; the nine remaining
+// stages of a block (3 passes x 3 radix-2 stages) touch only that wave's 2 KB, so they need
+// no workgroup barrier at all (LDS is in-order within a wave), and the finished block goes
+// straight to HBM (a wave stores 2 KB contiguous).  The inverse mirrors it.
+//
+// Same lazy butterflies, twiddle tables and results as ntt_lds.h (bit-identical outputs).
+#pragma once
+
+#include "ntt_lds.h"
+
+namespace ntt14 {
+constexpr int LOGN = 14;
+constexpr uint32_t N = 1u << LOGN;
+constexpr uint32_t T = 512;                 // threads = 8 waves
+constexpr int R0 = 32;                      // elements per thread in the register pass (5 stages)
+constexpr uint32_t BLK = 512;               // sub-transform size after 5 stages
+constexpr uint32_t BLK_PAD = BLK + 64;      // +8 words per 64: strided set reads stay conflict-free
+constexpr uint32_t GROUP_WORDS = 8 * BLK_PAD;
+
+__device__ __forceinline__ uint32_t pad64(uint32_t pos) { return pos + ((pos >> 6) << 3); }
+
+// LDS ops of one wave execute in order; this only stops the compiler from moving them
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename W>
+__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
+    fwd_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+               uint32_t L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W *xs = reinterpret_cast<W *>(smem);  // [2][8][BLK_PAD]
+    typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
+    constexpr int VN = 16 / sizeof(W);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q), twoq = q + q;
+    const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
+    const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
+    W *g = data + vec * N;
+
+    // stages 0..4 in registers: element tid of each of the 32 blocks
+    W h[R0];
+#pragma unroll
+    for (int u = 0; u < R0; ++u) h[u] = g[tid + T * u];
+    ct_network_lazy<W, 5>(h, tw, 0, 0, q, twoq);
+
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        W *x = xs + (grp & 1) * GROUP_WORDS;
+        // transpose through LDS: block (8*grp + m) receives its element `tid`
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m * BLK_PAD + pad64(tid)] = h[8 * grp + m];
+        __syncthreads();
+        W *xb = x + wave * BLK_PAD;            // from here on this wave owns block B alone
+        const uint32_t B = 8u * grp + wave;
+        W v[8];
+        {   // stages 5,6,7: sets {lane + 64 m}; twiddles are wave-uniform
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = xb[lane + 72 * m];
+            ct_network_lazy<W, 3>(v, tw, B, 5, q, twoq);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) xb[lane + 72 * m] = v[m];
+        }
+        wave_sync();
+        {   // stages 8,9,10: sets {64 c + j + 8 m}, c = lane/8, j = lane%8
+            const uint32_t c = lane >> 3, j = lane & 7u;
+            const uint32_t base = 72 * c + j;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m];
+            ct_network_lazy<W, 3>(v, tw, B * 8u + c, 8, q, twoq);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) xb[base + 8 * m] = v[m];
+        }
+        wave_sync();
+        {   // stages 11,12,13: 8 contiguous words per lane, then canonical form and out to HBM
+            const uint32_t base = pad64(8 * lane);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = xb[base + m];
+            ct_network_lazy<W, 3>(v, tw, B * 64u + lane, 11, q, twoq);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = csub<W>(fold_2q<W>(v[m], q, muw), q);
+            W *dst = g + B * BLK + 8 * lane;
+#pragma unroll
+            for (int m = 0; m < 8; m += VN) *reinterpret_cast<V16 *>(dst + m) = *reinterpret_cast<const V16 *>(&v[m]);
+        }
+        // the other buffer is used next; this one is rewritten two groups later, behind the
+        // next group's barrier
+    }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
+    inv_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+               uint32_t L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W *xs = reinterpret_cast<W *>(smem);
+    typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
+    constexpr int VN = 16 / sizeof(W);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q);
+    const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
+    const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
+    W *g = data + vec * N;
+
+    W h[R0];
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        W *x = xs + (grp & 1) * GROUP_WORDS;
+        W *xb = x + wave * BLK_PAD;
+        const uint32_t B = 8u * grp + wave;
+        W v[8];
+        {   // stages 13,12,11 on 8 contiguous words per lane, straight from HBM
+            const W *src = g + B * BLK + 8 * lane;
+#pragma unroll
+            for (int m = 0; m < 8; m += VN) *reinterpret_cast<V16 *>(&v[m]) = *reinterpret_cast<const V16 *>(src + m);
+            gs_network_lazy<W, 3, false>(v, tw, B * 64u + lane, 11, q, lc);
+            gs_fold<W, 3>(v, q, muw);
+            const uint32_t base = pad64(8 * lane);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) xb[base + m] = v[m];
+        }
+        wave_sync();
+        {   // stages 10,9,8
+            const uint32_t c = lane >> 3, j = lane & 7u;
+            const uint32_t base = 72 * c + j;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m];
+            gs_network_lazy<W, 3, false>(v, tw, B * 8u + c, 8, q, lc);
+            gs_fold<W, 3>(v, q, muw);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) xb[base + 8 * m] = v[m];
+        }
+        wave_sync();
+        {   // stages 7,6,5 (wave-uniform twiddles)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = xb[lane + 72 * m];
+            gs_network_lazy<W, 3, false>(v, tw, B, 5, q, lc);
+            gs_fold<W, 3>(v, q, muw);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) xb[lane + 72 * m] = v[m];
+        }
+        __syncthreads();
+        // transpose back: element `tid` of each of the group's 8 blocks
+#pragma unroll
+        for (int m = 0; m < 8; ++m) h[8 * grp + m] = x[m * BLK_PAD + pad64(tid)];
+    }
+    // stages 4..0 in registers (N^-1 folded into the last one), coalesced per u
+    gs_network_lazy<W, 5, true>(h, tw, 0, 0, q, lc);
+#pragma unroll
+    for (int u = 0; u < R0; ++u) g[tid + T * u] = csub<W>(h[u], q);
+}
+
+static inline size_t lds_bytes(size_t word) { return 2 * GROUP_WORDS * word; }
+}  // namespace ntt14

@@ -140,7 +140,7 @@ struct LdsOff {
 template <typename W, int LOGN, int LOGR, int WAVES_PER_EU>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
-                        uint32_t L, uint32_t stagger_blocks) {
+                        uint32_t L) {
     typedef NttLdsCfg<W, LOGN, LOGR, false> Cfg;
     constexpr uint32_t N = Cfg::N, T = Cfg::T;
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
@@ -154,10 +154,6 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     const W q = static_cast<W>(lc.q), twoq = q + q;
     const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
     W *g = data + vec * N;
-    // first generation of workgroups: stagger the second resident workgroup of each CU by about
-    // half a vector so that one streams from HBM while the other computes
-    if (blockIdx.x < stagger_blocks && (blockIdx.x & 1)) __builtin_amdgcn_s_sleep(100);
-
     {   // pass 0: stages [0, LOGR), elements tid + T*u straight from HBM (coalesced per u)
         W v[R];
 #pragma unroll

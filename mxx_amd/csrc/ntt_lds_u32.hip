@@ -1,5 +1,5 @@
 // ntt_lds_u32.hip — instantiations of the lazy LDS NTT for 32-bit residue words.
-#include "ntt_lds.h"
+#include "ntt14.h"
 
 #include <atomic>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 // ntt_lds_u64.hip — instantiations of the lazy LDS NTT for 64-bit residue words.
-#include "ntt_lds.h"
+#include "ntt14.h"
 
 #include <atomic>
 #include <cstdlib>

@@ -95,6 +95,25 @@ def test_ntt_n16384_bench_moduli(gpu, oracle):
     assert np.array_equal(m.to_rns(), x)
 
 
+def test_ntt_n16384_both_kernel_designs(gpu, oracle):
+    """grouped (ntt14.h, default) and whole-vector-in-LDS (ntt_lds.h) 2^14 kernels give identical bits."""
+    n = 16384
+    p = make_params(gpu, oracle, n, 4, 24, 12)
+    moduli = p.moduli()
+    x = rand_matrix(oracle, 6, 3, 3, moduli, n)
+    want = oracle.matrix_ntt(x, moduli)
+    for design in ("grouped", "whole"):
+        os.environ["MXX_HIP_NTT14"] = design
+        try:
+            m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+            m.ntt_all_in_place()
+            assert np.array_equal(m.to_rns(), want), design
+            m.intt_all_in_place()
+            assert np.array_equal(m.to_rns(), x), design
+        finally:
+            del os.environ["MXX_HIP_NTT14"]
+
+
 def test_ntt_n16384_u64(gpu, oracle):
     n = 16384
     p = make_params(gpu, oracle, n, 2, 51, 17)
