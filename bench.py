@@ -163,7 +163,7 @@ def main():
 
         units_per_step = batch
         metric, unit = "dcrt_ring_ops_per_s", "ring-ops/s"
-        kernel_name = "ntt_lds_kernel<uint32_t,14,5,false> (forward negacyclic NTT)"
+        kernel_name = "ntt14::fwd_kernel<uint32_t> (forward negacyclic NTT, 2^14 points)"
         algo_bytes = 2.0 * n * word * batch * L  # 2*n*w per (poly, limb)
         workload_desc = f"M1: n=2^14, L=4 (24-bit), batch {batch} polys; step = x<-INTT(NTT(x) o w) = {batch} ring mults"
     elif wl in ("m2a", "m2b"):

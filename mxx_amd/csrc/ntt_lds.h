@@ -1,10 +1,12 @@
 // ntt_lds.h — the tuned, LDS-resident negacyclic NTT / INTT kernels (one workgroup per
 // (polynomial, RNS limb) vector), with lazy (Harvey-style) butterflies.
 //
-// gfx950 issues an integer wave64 VALU instruction in ~4 cycles per SIMD (measured,
-// tools/valu_rates.hip: v_mul_hi_u32 4.8, v_mul_u32_u24 4.0, v_sub+v_min 8.2 for two),
-// so a 2^14-point transform is VALU-bound unless a butterfly costs <= ~6 instructions.
-// The butterflies therefore keep values in redundant form:
+// A 2^14-point transform is 114 688 butterflies per vector; on gfx950 a wave64 32-bit
+// integer multiply (v_mul_lo/hi_u32, v_mad_u64_u32) costs ~3.7-4 SIMD cycles and an add ~2
+// (tools/bfly_rates.hip: 15-19 cycles per 5-instruction butterfly per wave), which makes the
+// kernel VALU-bound, not HBM-bound: the arithmetic alone takes longer than the 80 us the
+// loads, LDS passes, barriers and stores take with the butterflies removed.  Every VALU
+// instruction removed counts, so the butterflies keep values in redundant form:
 //   forward (Cooley-Tukey):  nT = V*(-w) + hi(V*w')*q   (== -(V*w mod q), |.| < 2q)
 //                            A = U - nT ; B = U + 2q + nT            -> 5 VALU ops
 //       bounds only grow by 2q per stage, so no correction until the very end

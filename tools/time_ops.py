@@ -1,0 +1,30 @@
+"""Time individual ABI calls at BASELINE shapes (hipEvent marks on the engine stream)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mxx_amd as mx
+
+n = 16384
+def timed(ctx, fn, reps=3):
+    fn()
+    mx.gpu_device_sync()
+    best = 1e9
+    for _ in range(reps):
+        ctx.timer_start(); r = fn(); ms = ctx.timer_stop(); best = min(best, ms)
+    return best
+
+which = sys.argv[1] if len(sys.argv) > 1 else "dec"
+if which == "dec":
+    p = mx.GpuDCRTPolyParams(n, mx.gen_crt_basis(n, 8, 24), 12)
+    us = mx.GpuDCRTPolyUniformSampler()
+    M = us.sample_uniform(p, 64, 64, mx.DistType.FinRingDist())
+    ctx = p.ctx()
+    k = p.modulus_digits()
+    print("decompose 64x64 -> %dx64 (EVAL in, EVAL out): %.2f ms" % (64 * k, timed(ctx, lambda: M.decompose())))
+    Mc = M.clone().into_coeff_domain()
+    out = mx.GpuDCRTPolyMatrix(p, 64 * k, 64, 7, False)
+    from mxx_amd import _ffi
+    print("decompose kernel only (COEFF in, COEFF out): %.2f ms" % timed(ctx, lambda: _ffi.check_status(_ffi.lib().gpu_matrix_decompose_base(Mc.raw, 12, out.raw), "dec")))
+    S = us.sample_uniform(p, 8, 64 * k, mx.DistType.FinRingDist())
+    print("mul_decompose (8 x %d) * G^-1(64x64), chunk 1: %.2f ms" % (64 * k, timed(ctx, lambda: S.mul_decompose(M), 1)))
+    os.environ["MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"] = "64"
+    print("mul_decompose chunk 64: %.2f ms" % timed(ctx, lambda: S.mul_decompose(M), 2))
