@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 struct ChaChaRng {
     uint32_t state[16];
@@ -38,7 +39,7 @@ struct ChaChaRng {
 #define RNG_RING_WORDS 16
 #define RNG_LDS_BYTES(threads) ((threads) * RNG_RING_WORDS * sizeof(uint64_t))
 
-__device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
 #define CHACHA_QR(a, b, c, d) \
     a += b; d ^= a; d = rotl32(d, 16); \
@@ -46,7 +47,7 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) 
     a += b; d ^= a; d = rotl32(d, 8);  \
     c += d; b ^= c; b = rotl32(b, 7);
 
-__device__ __forceinline__ void chacha_rounds(uint32_t (&x)[16]) {
+__host__ __device__ __forceinline__ void chacha_rounds(uint32_t (&x)[16]) {
 #pragma unroll 1
     for (int i = 0; i < 10; ++i) {
         CHACHA_QR(x[0], x[4], x[8], x[12])
@@ -60,12 +61,15 @@ __device__ __forceinline__ void chacha_rounds(uint32_t (&x)[16]) {
     }
 }
 
-// ring_base: the block's LDS array of blockDim.x * 16 u64; call from every lane
-__device__ __forceinline__ void rng_init(ChaChaRng &rng, uint64_t *ring_base, const GpuRngSeed &seed, uint64_t stream0,
-                                         uint64_t stream1, uint64_t stream2, uint64_t domain_tag) {
+// HChaCha20 sub-key of a stream family: depends on (seed, domain tag, stream2) only, so a kernel
+// whose stream2 is constant (or takes few values) derives it once instead of once per coefficient
+struct ChaChaKey {
+    uint32_t w[8];
+};
+
+__host__ __device__ __forceinline__ ChaChaKey chacha_subkey(const GpuRngSeed &seed, uint64_t stream2, uint64_t domain_tag) {
     uint32_t x[16];
     x[0] = 0x61707865u; x[1] = 0x3320646eu; x[2] = 0x79622d32u; x[3] = 0x6b206574u;
-#pragma unroll
     for (int i = 0; i < 4; ++i) {
         x[4 + 2 * i] = static_cast<uint32_t>(seed.words[i]);
         x[5 + 2 * i] = static_cast<uint32_t>(seed.words[i] >> 32);
@@ -75,9 +79,18 @@ __device__ __forceinline__ void rng_init(ChaChaRng &rng, uint64_t *ring_base, co
     x[14] = static_cast<uint32_t>(stream2);
     x[15] = static_cast<uint32_t>(stream2 >> 32);
     chacha_rounds(x);  // HChaCha20: no feed-forward, subkey = words 0..3 and 12..15
+    ChaChaKey k;
+    k.w[0] = x[0]; k.w[1] = x[1]; k.w[2] = x[2]; k.w[3] = x[3];
+    k.w[4] = x[12]; k.w[5] = x[13]; k.w[6] = x[14]; k.w[7] = x[15];
+    return k;
+}
+
+// ring_base: the block's LDS array of blockDim.x * 16 u64; call from every lane
+__device__ __forceinline__ void rng_init_keyed(ChaChaRng &rng, uint64_t *ring_base, const ChaChaKey &key,
+                                               uint64_t stream0, uint64_t stream1) {
     rng.state[0] = 0x61707865u; rng.state[1] = 0x3320646eu; rng.state[2] = 0x79622d32u; rng.state[3] = 0x6b206574u;
-    rng.state[4] = x[0]; rng.state[5] = x[1]; rng.state[6] = x[2]; rng.state[7] = x[3];
-    rng.state[8] = x[12]; rng.state[9] = x[13]; rng.state[10] = x[14]; rng.state[11] = x[15];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rng.state[4 + i] = key.w[i];
     rng.state[12] = static_cast<uint32_t>(stream0);
     rng.state[13] = static_cast<uint32_t>(stream0 >> 32);
     rng.state[14] = static_cast<uint32_t>(stream1);
@@ -87,6 +100,22 @@ __device__ __forceinline__ void rng_init(ChaChaRng &rng, uint64_t *ring_base, co
     rng.head = 0;
     rng.tail = 0;
 }
+
+__device__ __forceinline__ void rng_init(ChaChaRng &rng, uint64_t *ring_base, const GpuRngSeed &seed, uint64_t stream0,
+                                         uint64_t stream1, uint64_t stream2, uint64_t domain_tag) {
+    rng_init_keyed(rng, ring_base, chacha_subkey(seed, stream2, domain_tag), stream0, stream1);
+}
+
+// Re-key an open generator to another stream of the same family; buffered words are dropped
+__device__ __forceinline__ void rng_reopen(ChaChaRng &rng, uint64_t stream0, uint64_t stream1) {
+    rng.state[12] = static_cast<uint32_t>(stream0);
+    rng.state[13] = static_cast<uint32_t>(stream0 >> 32);
+    rng.state[14] = static_cast<uint32_t>(stream1);
+    rng.state[15] = static_cast<uint32_t>(stream1 >> 32);
+    rng.head = rng.tail;
+}
+
+__device__ __forceinline__ uint32_t rng_avail(const ChaChaRng &rng) { return rng.tail - rng.head; }
 
 // Checkpoint: guarantees >= 8 words are available.  Call at wave-convergent points, at least
 // once per 8 draws.
@@ -271,4 +300,171 @@ static __device__ int64_t sample_integer_karney(ChaChaRng &rng, double mean, dou
         result = static_cast<int64_t>(llround(mean + stddev * rng_standard_normal(rng)));
     }
     return result;
+}
+
+
+// coefficients per lane for the persistent-lane kernels: fill the chip first, then up to 16 per
+// lane; MXX_HIP_SAMPLER_PER_LANE=n forces n (tests use it to exercise stream switching at small sizes)
+static inline uint32_t sampler_per_lane(size_t total, size_t chip_lanes) {
+    if (const char *env = std::getenv("MXX_HIP_SAMPLER_PER_LANE")) {
+        const int v = std::atoi(env);
+        if (v >= 1 && v <= 64) return static_cast<uint32_t>(v);
+    }
+    const size_t per = total / chip_lanes;
+    return static_cast<uint32_t>(per < 1 ? 1 : (per > 16 ? 16 : per));
+}
+
+// ---- Persistent-lane form of the same sampler ---------------------------------------------------
+// A lane works through a list of coefficients; the wave steps all lanes together:
+//   every step      : lanes in the cheap states (H*, B*) consume one keystream word;
+//   every 4th step  : the expensive transitions (sign + offset draw with its three divisions
+//                     and the 64-bit modulo, the normal fallback, and the caller's
+//                     "sample finished" action) run for the lanes parked in them;
+//   every 8th step  : keystream refill (all live lanes together).
+// A lane only consumes words it holds (rng_avail), so the per-stream draw order - and therefore
+// every sample - is that of sample_integer_karney above.  A wave now pays max-over-lanes of the
+// SUM of the draw counts of its lanes' coefficients (which concentrates around the mean) instead
+// of the per-coefficient maximum, and the expensive code runs a quarter as often.
+enum { KS_H0 = 0, KS_H1, KS_H2, KS_B0, KS_B1, KS_SIGN, KS_FALLBACK, KS_DONE, KS_IDLE };
+
+struct KarneyFsm {
+    int32_t st, k, p_left, b_left, bn, iter;
+    bool in_p;
+    double ha, hb, x, y, zz, bthr;
+    double mean, stddev;
+    uint64_t cs, magic;  // ceil(stddev) and floor((2^64-1)/cs)
+    int64_t result;
+};
+
+struct KarneyDivisor {
+    uint64_t cs, magic;
+    bool degenerate;  // the sampler returns llround(mean) without drawing
+};
+
+__host__ __device__ __forceinline__ KarneyDivisor karney_divisor(double stddev) {
+    KarneyDivisor d{0, 0, true};
+    if (!(stddev > 0.0) || !(stddev <= 1.7976931348623157e308)) return d;  // also rejects NaN and +inf
+    const int64_t c = static_cast<int64_t>(ceil(stddev));
+    if (c <= 0) return d;
+    d.cs = static_cast<uint64_t>(c);
+    d.magic = ~0ull / d.cs;
+    d.degenerate = false;
+    return d;
+}
+
+__device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double stddev, const KarneyDivisor &d) {
+    f.mean = mean;
+    f.stddev = stddev;
+    if (d.degenerate || !isfinite(mean)) {
+        f.result = static_cast<int64_t>(llround(mean));
+        f.st = KS_DONE;
+        return;
+    }
+    f.cs = d.cs;
+    f.magic = d.magic;
+    f.st = KS_H0;
+    f.k = 0;
+    f.in_p = false;
+    f.iter = 0;
+}
+
+__device__ __forceinline__ void karney_restart(KarneyFsm &f) {
+    if (++f.iter >= (1 << 16)) {
+        f.st = KS_FALLBACK;
+    } else {
+        f.k = 0;
+        f.in_p = false;
+        f.st = KS_H0;
+    }
+}
+
+// one cheap step
+__device__ __forceinline__ void karney_light(KarneyFsm &f, ChaChaRng &rng) {
+    if (f.st > KS_B1 || rng_avail(rng) == 0) return;
+    const double u = u64_to_open01(rng_next_u64(rng));
+    if (f.st <= KS_H2) {
+        int hres = -1;
+        if (f.st == KS_H0) {
+            f.ha = u;
+            if (!(u < 0.5)) hres = 1; else f.st = KS_H1;
+        } else if (f.st == KS_H1) {
+            f.hb = u;
+            if (!(f.hb < f.ha)) hres = 0; else f.st = KS_H2;
+        } else {
+            f.ha = u;
+            if (!(f.ha < f.hb)) hres = 1; else f.st = KS_H1;
+        }
+        if (hres >= 0) {
+            if (!f.in_p) {  // G: count successes
+                bool g_done = hres == 0;
+                if (hres == 1) {
+                    ++f.k;
+                    if (f.k > 1024) g_done = true;
+                }
+                if (g_done) {
+                    f.p_left = f.k * (f.k - 1);
+                    if (f.p_left == 0) f.st = KS_SIGN;
+                    else { f.in_p = true; f.st = KS_H0; }
+                } else {
+                    f.st = KS_H0;
+                }
+            } else if (hres == 1) {  // P: needs p_left successes
+                f.st = (--f.p_left == 0) ? KS_SIGN : KS_H0;
+            } else {
+                karney_restart(f);
+            }
+        }
+    } else {
+        int bres = -1;
+        if (f.st == KS_B0) {
+            f.zz = u;
+            if (!(f.zz < f.y)) bres = (f.bn % 2) == 0; else f.st = KS_B1;
+        } else {
+            if (!(u < f.bthr)) {
+                bres = (f.bn % 2) == 0;
+            } else {
+                f.y = f.zz;
+                if (f.bn > 4096) bres = (f.bn % 2) == 0;
+                else { ++f.bn; f.st = KS_B0; }
+            }
+        }
+        if (bres == 1) {
+            if (--f.b_left == 0) {
+                f.st = KS_DONE;
+            } else {
+                f.y = f.x;
+                f.bn = 0;
+                f.st = KS_B0;
+            }
+        } else if (bres == 0) {
+            karney_restart(f);
+        }
+    }
+}
+
+// the expensive transitions; call at wave-convergent service points
+__device__ __forceinline__ void karney_heavy(KarneyFsm &f, ChaChaRng &rng) {
+    if (f.st == KS_SIGN && rng_avail(rng) >= 2) {
+        const uint64_t w1 = rng_next_u64(rng), w2 = rng_next_u64(rng);
+        const int64_t s = (w1 & 1ull) ? 1 : -1;
+        const double di0 = f.stddev * static_cast<double>(f.k) + static_cast<double>(s) * f.mean;
+        const int64_t i0 = static_cast<int64_t>(ceil(di0));
+        const double x0 = (static_cast<double>(i0) - di0) / f.stddev;
+        uint64_t j = w2 - __umul64hi(w2, f.magic) * f.cs;  // w2 % cs
+        while (j >= f.cs) j -= f.cs;
+        f.x = x0 + static_cast<double>(static_cast<int64_t>(j)) / f.stddev;
+        if (!(f.x < 1.0) || (f.x == 0.0 && s < 0 && f.k == 0)) {
+            karney_restart(f);
+        } else {
+            f.b_left = f.k + 1;
+            f.bthr = (2.0 * static_cast<double>(f.k) + f.x) / static_cast<double>(2 * f.k + 2);
+            f.y = f.x;
+            f.bn = 0;
+            f.result = s * (i0 + static_cast<int64_t>(j));
+            f.st = KS_B0;
+        }
+    } else if (f.st == KS_FALLBACK && rng_avail(rng) >= 2) {
+        f.result = static_cast<int64_t>(llround(f.mean + f.stddev * rng_standard_normal(rng)));
+        f.st = KS_DONE;
+    }
 }

@@ -13,16 +13,26 @@
 #include "modarith.h"
 #include "rng.h"
 
+#include <algorithm>
+
 static constexpr uint64_t kTagUniform = 0x6f70656e66686531ull;
 static constexpr uint64_t kTagGauss = 0x6f70656e66686532ull;
 static constexpr uint64_t kTagBit = 0x6f70656e66686533ull;
 static constexpr uint64_t kTagTernary = 0x6f70656e66686534ull;
 
+// uniform / bit / ternary: one short stream per coefficient (and per limb for uniform).  The
+// HChaCha20 sub-keys depend on the limb only, so the block derives them once into LDS.
 template <typename W>
 __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
                                            size_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L,
-                                           uint32_t N, int dist, double sigma, GpuRngSeed seed) {
+                                           uint32_t N, int dist, GpuRngSeed seed) {
     __shared__ uint64_t ring[256 * RNG_RING_WORDS];
+    __shared__ ChaChaKey keys[GPUPOLY_MAX_LIMBS];
+    const bool uniform = dist == GPU_MATRIX_DIST_UNIFORM;
+    if (threadIdx.x < (uniform ? L : 1u))
+        keys[threadIdx.x] = uniform ? chacha_subkey(seed, static_cast<uint64_t>(threadIdx.x) + 1, kTagUniform)
+                                    : chacha_subkey(seed, 0, dist == GPU_MATRIX_DIST_BIT ? kTagBit : kTagTernary);
+    __syncthreads();
     const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= polys * N) return;
     const size_t p = idx / N;
@@ -31,29 +41,69 @@ __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict_
     const uint64_t gpoly = row * full_ncol + col_offset + lcol;
     W *dst = out + p * L * N + i;
     ChaChaRng rng;
-    if (dist == GPU_MATRIX_DIST_UNIFORM) {
+    if (uniform) {
         for (uint32_t l = 0; l < L; ++l) {
-            rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, static_cast<uint64_t>(l) + 1, kTagUniform);
+            rng_init_keyed(rng, ring, keys[l], gpoly + 1, static_cast<uint64_t>(i) + 1);
             dst[static_cast<size_t>(l) * N] = static_cast<W>(rng_uniform_mod(rng, limbs[l].q));
         }
         return;
     }
+    rng_init_keyed(rng, ring, keys[0], gpoly + 1, static_cast<uint64_t>(i) + 1);
+    rng_fill(rng);
     int64_t z;
-    if (dist == GPU_MATRIX_DIST_GAUSS) {
-        rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagGauss);
-        z = sample_integer_karney(rng, 0.0, sigma);
-    } else if (dist == GPU_MATRIX_DIST_BIT) {
-        rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagBit);
-        rng_fill(rng);
+    if (dist == GPU_MATRIX_DIST_BIT) {
         z = static_cast<int64_t>(rng_next_u64(rng) & 1ull);
     } else {
-        rng_init(rng, ring, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagTernary);
-        rng_fill(rng);
         const uint64_t pick = rng_next_u64(rng) % 3ull;
         z = pick == 0 ? 0 : (pick == 1 ? 1 : -1);
     }
     for (uint32_t l = 0; l < L; ++l)
-        dst[static_cast<size_t>(l) * N] = signed_to_residue<W>(z, static_cast<W>(limbs[l].q));
+        dst[static_cast<size_t>(l) * N] = signed_to_residue_mu<W>(z, limbs[l].q, limbs[l].mu64);
+}
+
+// discrete Gaussian: persistent lanes (rng.h).  Lane `tid` of block b owns coefficients
+// b*256*per_lane + e*256 + tid, e < per_lane, each with its own stream (sub-key shared by all).
+template <typename W>
+__global__ void __launch_bounds__(256) sample_gauss_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
+                                    size_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L, uint32_t N,
+                                    double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane) {
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
+    const size_t total = polys * N;
+    const size_t first = static_cast<size_t>(blockIdx.x) * 256u * per_lane + threadIdx.x;
+    ChaChaRng rng;
+    rng_init_keyed(rng, ring, key, 0, 0);
+    KarneyFsm f;
+    f.st = KS_DONE;
+    uint32_t e = ~0u;  // nothing sampled yet
+    size_t idx = 0;
+    for (uint32_t step = 0;; ++step) {
+        if ((step & 3) == 0) {
+            if (f.st == KS_DONE) {
+                if (e != ~0u) {
+                    const size_t p = idx / N;
+                    W *dst = out + p * L * N + (idx - p * N);
+                    for (uint32_t l = 0; l < L; ++l)
+                        dst[static_cast<size_t>(l) * N] = signed_to_residue_mu<W>(f.result, limbs[l].q, limbs[l].mu64);
+                }
+                ++e;
+                idx = first + static_cast<size_t>(e) * 256u;
+                if (e < per_lane && idx < total) {
+                    const size_t p = idx / N;
+                    const size_t row = p / local_ncol, lcol = p - row * local_ncol;
+                    rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx - p * N) + 1);
+                    karney_begin(f, 0.0, sigma, div);
+                } else {
+                    f.st = KS_IDLE;
+                }
+            }
+            if ((step & 7) == 0) {
+                if (__all(f.st == KS_IDLE)) break;
+                if (f.st != KS_IDLE) rng_fill(rng);
+            }
+            karney_heavy(f, rng);
+        }
+        karney_light(f, rng);
+    }
 }
 
 static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t full_ncol, size_t col_offset) {
@@ -71,15 +121,33 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
     if (ctx_activate(ctx)) return 1;
     const size_t total = polys * static_cast<size_t>(ctx->N);
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
-    const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
-    if (ctx->wide)
-        hipLaunchKernelGGL(sample_distribution_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                           static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset, L,
-                           (uint32_t)ctx->N, dist, sigma, seed);
-    else
-        hipLaunchKernelGGL(sample_distribution_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                           static_cast<uint32_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset, L,
-                           (uint32_t)ctx->N, dist, sigma, seed);
+    const uint32_t N = static_cast<uint32_t>(ctx->N);
+    if (dist == GPU_MATRIX_DIST_GAUSS) {
+        // enough lanes to fill the chip first, then up to 16 coefficients per lane
+        const size_t chip_lanes = 256u * 256u * 5u;
+        const uint32_t per_lane = sampler_per_lane(total, chip_lanes);
+        const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
+        const KarneyDivisor div = karney_divisor(sigma);
+        const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
+        if (ctx->wide)
+            hipLaunchKernelGGL(sample_gauss_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
+                               L, N, sigma, div, key, per_lane);
+        else
+            hipLaunchKernelGGL(sample_gauss_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<uint32_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
+                               L, N, sigma, div, key, per_lane);
+    } else {
+        const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+        if (ctx->wide)
+            hipLaunchKernelGGL(sample_distribution_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
+                               L, N, dist, seed);
+        else
+            hipLaunchKernelGGL(sample_distribution_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               static_cast<uint32_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
+                               L, N, dist, seed);
+    }
     HIP_TRY(hipGetLastError());
     // samples are coefficients; callers always get EVAL (MatrixSampling.cu:463-469)
     return launch_ntt(ctx, out->data, polys * L, static_cast<int>(L), false);

@@ -19,6 +19,7 @@
 #include "rng.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 static constexpr uint64_t kTagGadget = 0x6761646765746731ull;
 static constexpr uint64_t kTagP1 = 0x7065727475726231ull;
@@ -137,15 +138,237 @@ __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out,
             const size_t orow = r * k + static_cast<size_t>(t) * dpt + d;
             const size_t opoly = orow * src_cols + col;
             for (uint32_t l = 0; l < L; ++l)
-                out[(opoly * L + l) * N + i] = signed_to_residue<W>(digit, static_cast<W>(limbs[l].q));
+                out[(opoly * L + l) * N + i] = signed_to_residue_mu<W>(digit, limbs[l].q, limbs[l].mu64);
         }
     }
+}
+
+// ---- G-lattice sampler, persistent-lane form (dpt <= 4; rng.h explains the scheme) -------------
+// The stream of element (p, t, i) is keyed by stream2 = i+1, so its HChaCha20 sub-key depends on
+// the coefficient index only: one table of N sub-keys per call instead of one derivation per element.
+__global__ void gadget_keys_kernel(ChaChaKey *__restrict__ keys, uint32_t N, GpuRngSeed seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) keys[i] = chacha_subkey(seed, static_cast<uint64_t>(i) + 1, kTagGadget);
+}
+
+// Pass 1, fully convergent: the dpt normals every element draws first (words 0..2*dpt-1 of its
+// stream) and the centres a_d they imply; a_out is [dpt][total].
+template <typename W, int MAXD>
+__global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict__ a_out, const W *__restrict__ src,
+                                       const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
+                                       size_t total, uint32_t L, uint32_t N, uint32_t dpt, uint32_t base_bits,
+                                       double c) {
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t i = static_cast<uint32_t>(idx % N);
+    const size_t pt = idx / N;
+    const uint32_t t = static_cast<uint32_t>(pt % L);
+    const size_t p = pt / L;
+    const uint64_t qt = limbs[t].q;
+    uint64_t value = static_cast<uint64_t>(src[idx]);
+    if (value >= qt) value %= qt;
+    const uint64_t base = 1ull << base_bits;
+    const double base_f = static_cast<double>(base);
+    const double sigma = c / (base_f + 1.0);
+    const double kf = static_cast<double>(dpt);
+
+    ChaChaRng rng;
+    rng_init_keyed(rng, ring, keys[i], static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1);
+    rng_fill(rng);  // 8 words >= 2 * MAXD
+    double zf[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) zf[d] = d < (int)dpt ? sigma * rng_standard_normal(rng) : 0.0;
+    double prev_a = 0.0;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+        if (d < (int)dpt) {
+            const double ld = d == 0 ? sqrt(base_f * (1.0 + 1.0 / kf) + 1.0)
+                                     : sqrt(base_f * (1.0 + 1.0 / (kf - static_cast<double>(d))));
+            double pd;
+            if (d + 1 < (int)dpt) {
+                const double hn = sqrt(base_f * (1.0 - 1.0 / (kf - static_cast<double>(d))));
+                pd = ld * zf[d] + hn * zf[d + 1 < MAXD ? d + 1 : d];
+            } else {
+                const double hd = d == 0 ? 0.0 : sqrt(base_f * (1.0 - 1.0 / (kf - static_cast<double>(d - 1))));
+                pd = hd * zf[d];
+            }
+            const double vd = static_cast<double>(static_cast<int64_t>((value >> (base_bits * d)) & (base - 1)));
+            const double ad = (prev_a + vd - pd) / base_f;
+            prev_a = ad;
+            a_out[static_cast<size_t>(d) * total + idx] = ad;
+        }
+    }
+}
+
+// Pass 2: the dpt Karney integers of every element.  Lane `tid` of block b owns elements
+// b*256*per_lane + e*256 + tid.  ph = index of the integer in flight (0: z_last, 1+d: z_d).
+template <typename W, int MAXD>
+__global__ void __launch_bounds__(256) gauss_samp_lanes_kernel(W *__restrict__ out, const W *__restrict__ src,
+                                        const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
+                                        const double *__restrict__ a_in, size_t total, uint32_t src_cols, uint32_t L,
+                                        uint32_t N, uint32_t dpt, uint32_t base_bits, double c, size_t k,
+                                        KarneyDivisor div_sigma, uint32_t per_lane) {
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
+    const uint64_t base = 1ull << base_bits;
+    const double base_f = static_cast<double>(base);
+    const double sigma = c / (base_f + 1.0);
+    const int last = static_cast<int>(dpt) - 1;
+    const size_t first = static_cast<size_t>(blockIdx.x) * 256u * per_lane + threadIdx.x;
+
+    ChaChaRng rng;
+    rng_init_keyed(rng, ring, ChaChaKey{}, 0, 0);
+    KarneyFsm f;
+    f.st = KS_DONE;
+    bool fin = true;
+    uint32_t e = ~0u, skip = 0, ph = 0;
+    size_t idx = 0;
+    uint64_t qt = 1, value = 0;
+    double a[MAXD];
+    int64_t z[MAXD];
+    int64_t z_last = 0;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) { a[d] = 0.0; z[d] = 0; }
+
+    for (uint32_t step = 0;; ++step) {
+        if ((step & 3) == 0) {
+            if (f.st == KS_DONE && !fin) {  // an integer of the current element is ready
+                if (ph == 0) {
+                    z_last = f.result;
+                    double prev_c = 0.0;
+#pragma unroll
+                    for (int d = 0; d < MAXD; ++d) {
+                        if (d < (int)dpt) {
+                            const double cd = (prev_c + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
+                            prev_c = cd;
+                            a[d] += static_cast<double>(z_last) * cd;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < MAXD; ++d)
+                        if (d == (int)ph - 1) z[d] = f.result;
+                }
+                ++ph;
+                if (ph == dpt) {
+                    fin = true;
+                } else {
+                    double an = 0.0;
+#pragma unroll
+                    for (int d = 0; d < MAXD; ++d)
+                        if (d == (int)ph - 1) an = a[d];
+                    karney_begin(f, -an, sigma, div_sigma);
+                }
+            }
+            if ((step & 7) == 0) {
+                if (f.st == KS_DONE && fin) {  // element complete: write its digits, take the next one
+                    if (e != ~0u) {
+                        const uint32_t i = static_cast<uint32_t>(idx % N);
+                        const size_t pt = idx / N;
+                        const uint32_t t = static_cast<uint32_t>(pt % L);
+                        const size_t p = pt / L;
+                        const size_t r = p / src_cols, col = p - r * src_cols;
+                        int64_t z_prev = 0;
+#pragma unroll
+                        for (int d = 0; d < MAXD; ++d) {
+                            if (d < (int)dpt) {
+                                const int64_t md = static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1));
+                                const int64_t vd = static_cast<int64_t>((value >> (base_bits * d)) & (base - 1));
+                                const int64_t zd = d < last ? z[d] : z_last;
+                                int64_t digit;
+                                if (dpt == 1) digit = static_cast<int64_t>(base) * zd + md * zd + vd;
+                                else if (d == 0) digit = static_cast<int64_t>(base) * zd + md * z_last + vd;
+                                else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
+                                else digit = md * z_last - z_prev + vd;
+                                z_prev = zd;
+                                const size_t orow = r * k + static_cast<size_t>(t) * dpt + d;
+                                const size_t opoly = orow * src_cols + col;
+                                for (uint32_t l = 0; l < L; ++l)
+                                    out[(opoly * L + l) * N + i] = signed_to_residue_mu<W>(digit, limbs[l].q, limbs[l].mu64);
+                            }
+                        }
+                    }
+                    ++e;
+                    idx = first + static_cast<size_t>(e) * 256u;
+                    if (e < per_lane && idx < total) {
+                        const uint32_t i = static_cast<uint32_t>(idx % N);
+                        const size_t pt = idx / N;
+                        const uint32_t t = static_cast<uint32_t>(pt % L);
+                        const size_t p = pt / L;
+                        qt = limbs[t].q;
+                        value = static_cast<uint64_t>(src[idx]);
+                        if (value >= qt) value %= qt;
+                        const ChaChaKey key = keys[i];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) rng.state[4 + w] = key.w[w];
+                        rng_reopen(rng, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1);
+                        skip = 2 * dpt;  // the normals of pass 1
+                        double c_last = 0.0, a_last = 0.0;
+#pragma unroll
+                        for (int d = 0; d < MAXD; ++d) {
+                            if (d < (int)dpt) {
+                                a[d] = a_in[static_cast<size_t>(d) * total + idx];
+                                c_last = (c_last + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
+                                a_last = a[d];
+                            }
+                        }
+                        ph = 0;
+                        fin = false;
+                        const double sd = sigma / c_last;
+                        karney_begin(f, -a_last / c_last, sd, karney_divisor(sd));
+                    } else {
+                        f.st = KS_IDLE;
+                    }
+                }
+                if (__all(f.st == KS_IDLE)) break;
+                if (f.st != KS_IDLE) rng_fill(rng);
+                rng.head += skip;
+                skip = 0;
+            }
+            karney_heavy(f, rng);
+        }
+        karney_light(f, rng);
+    }
+}
+
+template <typename W, int MAXD>
+static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t total, uint32_t src_cols, uint32_t L,
+                                   uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
+    const uint32_t N = static_cast<uint32_t>(ctx->N);
+    void *keys = nullptr, *a_buf = nullptr;
+    if (ctx_alloc(ctx, static_cast<size_t>(N) * sizeof(ChaChaKey), &keys) ||
+        ctx_alloc(ctx, total * dpt * sizeof(double), &a_buf)) {
+        ctx_free(ctx, keys);
+        return 1;
+    }
+    hipLaunchKernelGGL(gadget_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream,
+                       static_cast<ChaChaKey *>(keys), N, seed);
+    hipLaunchKernelGGL((gauss_samp_prep_kernel<W, MAXD>), dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       ctx->stream, static_cast<double *>(a_buf), src, ctx->d_limbs,
+                       static_cast<const ChaChaKey *>(keys), total, L, N, dpt, base_bits, c);
+    const size_t chip_lanes = 256u * 256u * 4u;
+    const uint32_t per_lane = sampler_per_lane(total, chip_lanes);
+    const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
+    const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
+    hipLaunchKernelGGL((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream, out, src,
+                       ctx->d_limbs, static_cast<const ChaChaKey *>(keys), static_cast<const double *>(a_buf), total,
+                       src_cols, L, N, dpt, base_bits, c, k, karney_divisor(sigma), per_lane);
+    const hipError_t err = hipGetLastError();
+    ctx_free(ctx, keys);
+    ctx_free(ctx, a_buf);
+    HIP_TRY(err);
+    return 0;
 }
 
 template <typename W>
 static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys, uint32_t src_cols, uint32_t L,
                              uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
     const size_t total = polys * L * static_cast<size_t>(ctx->N);
+    // MXX_HIP_GSAMP=simple keeps the one-thread-per-element kernel for every dpt (A/B runs, tests)
+    const char *mode = std::getenv("MXX_HIP_GSAMP");
+    const bool simple = mode && mode[0] == 's';
+    if (!simple && dpt <= 2) return launch_gauss_samp_lanes<W, 2>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
+    if (!simple && dpt <= 4) return launch_gauss_samp_lanes<W, 4>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
     const unsigned blocks = static_cast<unsigned>((total + 127) / 128);
     const uint32_t N = static_cast<uint32_t>(ctx->N);
 #define LAUNCH_GS(MAXD)                                                                                        \
@@ -282,7 +505,7 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
             const int64_t z = sample_integer_karney(rng, mu, sqrt_var[t]);
             for (uint32_t l = 0; l < L; ++l)
                 out[((static_cast<size_t>(t) * cols + col) * L + l) * N + i] =
-                    signed_to_residue<W>(z, static_cast<W>(limbs[l].q));
+                    signed_to_residue_mu<W>(z, limbs[l].q, limbs[l].mu64);
             const double delta = static_cast<double>(z) - mu;
 #pragma unroll
             for (int r = 0; r < MAXM; ++r)
@@ -298,7 +521,7 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
             const int64_t z = sample_integer_karney(rng, mu, sqrt_var[t]);
             for (uint32_t l = 0; l < L; ++l)
                 out[((static_cast<size_t>(t) * cols + col) * L + l) * N + i] =
-                    signed_to_residue<W>(z, static_cast<W>(limbs[l].q));
+                    signed_to_residue_mu<W>(z, limbs[l].q, limbs[l].mu64);
             const double delta = static_cast<double>(z) - mu;
             for (int r = 0; r < t; ++r) mean[r] += upd[t * m + r] * delta;
         }
