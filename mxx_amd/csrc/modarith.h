@@ -93,12 +93,18 @@ __device__ __forceinline__ W signed_to_residue(int64_t v, W q) {
     return rem == 0 ? static_cast<W>(0) : static_cast<W>(q - rem);
 }
 
-// same value as signed_to_residue without the 64-bit hardware-less `%`: mu64 = floor(2^64/q)
+// same value as signed_to_residue without the 64-bit `%` (no hardware divider): mu64 = floor(2^64/q)
 template <typename W>
 __device__ __forceinline__ W signed_to_residue_mu(int64_t v, uint64_t q, uint64_t mu64) {
     const uint64_t mag = v >= 0 ? static_cast<uint64_t>(v) : static_cast<uint64_t>(-(v + 1)) + 1;
-    uint64_t r = mag - __umul64hi(mag, mu64) * q;  // quotient estimate is at most 2 short
-    while (r >= q) r -= q;
+    uint64_t r = mag;
+    if (mag >= q) {
+        if ((mag >> 32) == 0)  // quotient estimate from the top word of mu64 alone
+            r = mag - static_cast<uint64_t>(__umulhi(static_cast<uint32_t>(mag), static_cast<uint32_t>(mu64 >> 32))) * q;
+        else
+            r = mag - __umul64hi(mag, mu64) * q;
+        while (r >= q) r -= q;  // either estimate is at most 3 short
+    }
     return static_cast<W>((v >= 0 || r == 0) ? r : q - r);
 }
 

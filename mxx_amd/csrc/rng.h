@@ -303,15 +303,22 @@ static __device__ int64_t sample_integer_karney(ChaChaRng &rng, double mean, dou
 }
 
 
-// coefficients per lane for the persistent-lane kernels: fill the chip first, then up to 16 per
-// lane; MXX_HIP_SAMPLER_PER_LANE=n forces n (tests use it to exercise stream switching at small sizes)
-static inline uint32_t sampler_per_lane(size_t total, size_t chip_lanes) {
+// Elements per workgroup chunk for the persistent-lane kernels: one resident round of the whole
+// chip when the problem is big enough (chunks are consumed dynamically inside a workgroup, so the
+// only imbalance left is the last element of each lane).  MXX_HIP_SAMPLER_PER_LANE=n forces n
+// elements per lane (tests use it to exercise stream switching at small sizes).
+static inline uint32_t sampler_per_lane(size_t total, const void *kernel, int device) {
     if (const char *env = std::getenv("MXX_HIP_SAMPLER_PER_LANE")) {
         const int v = std::atoi(env);
-        if (v >= 1 && v <= 64) return static_cast<uint32_t>(v);
+        if (v >= 1 && v <= 4096) return static_cast<uint32_t>(v);
     }
-    const size_t per = total / chip_lanes;
-    return static_cast<uint32_t>(per < 1 ? 1 : (per > 16 ? 16 : per));
+    int blocks_per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) != hipSuccess || blocks_per_cu < 1)
+        blocks_per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    const size_t lanes = static_cast<size_t>(blocks_per_cu) * cus * 256u;
+    const size_t per = (total + lanes - 1) / lanes;
+    return static_cast<uint32_t>(per < 1 ? 1 : (per > 4096 ? 4096 : per));
 }
 
 // ---- Persistent-lane form of the same sampler ---------------------------------------------------
@@ -325,16 +332,28 @@ static inline uint32_t sampler_per_lane(size_t total, size_t chip_lanes) {
 // every sample - is that of sample_integer_karney above.  A wave now pays max-over-lanes of the
 // SUM of the draw counts of its lanes' coefficients (which concentrates around the mean) instead
 // of the per-coefficient maximum, and the expensive code runs a quarter as often.
-enum { KS_H0 = 0, KS_H1, KS_H2, KS_B0, KS_B1, KS_SIGN, KS_FALLBACK, KS_DONE, KS_IDLE };
+// Cheap states all have the shape "draw u; continue while u < T":
+//   H (Bernoulli e^-1/2): T starts at 1/2 and becomes the last draw; the outcome is the parity
+//      of the run length (the H0/H1/H2 states of the sequential form collapse into T + parity);
+//   B0: T = y, B1: T = (2k+x)/(2k+2) - the two alternating comparisons of B(k, x).
+// Every uniform is m * 2^-53 with the integer m = max(word >> 11, 1), so "u < T" is decided
+// exactly on integers: m < ceil(T * 2^53) (scaling by 2^53 is exact).  The cheap path is
+// therefore integer-only; doubles appear in the expensive transitions alone.
+enum { KS_H = 0, KS_B0, KS_B1, KS_SIGN, KS_FALLBACK, KS_DONE, KS_IDLE };
 
 struct KarneyFsm {
-    int32_t st, k, p_left, b_left, bn, iter;
+    int32_t st, k, p_left, b_left, bn, iter, par;
     bool in_p;
-    double ha, hb, x, y, zz, bthr;
+    uint64_t T, xt, bt, zz;  // thresholds / last draw in units of 2^-53: current, x, (2k+x)/(2k+2), z
     double mean, stddev;
     uint64_t cs, magic;  // ceil(stddev) and floor((2^64-1)/cs)
     int64_t result;
 };
+
+#define KARNEY_HALF (1ull << 52)
+
+// t in [0, 1] -> ceil(t * 2^53)
+__device__ __forceinline__ uint64_t karney_ticks(double t) { return static_cast<uint64_t>(ceil(t * 9007199254740992.0)); }
 
 struct KarneyDivisor {
     uint64_t cs, magic;
@@ -362,84 +381,66 @@ __device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double s
     }
     f.cs = d.cs;
     f.magic = d.magic;
-    f.st = KS_H0;
+    f.st = KS_H;
+    f.T = KARNEY_HALF;
+    f.par = 0;
     f.k = 0;
     f.in_p = false;
     f.iter = 0;
 }
 
-__device__ __forceinline__ void karney_restart(KarneyFsm &f) {
-    if (++f.iter >= (1 << 16)) {
-        f.st = KS_FALLBACK;
-    } else {
-        f.k = 0;
-        f.in_p = false;
-        f.st = KS_H0;
-    }
-}
-
 // one cheap step
 __device__ __forceinline__ void karney_light(KarneyFsm &f, ChaChaRng &rng) {
     if (f.st > KS_B1 || rng_avail(rng) == 0) return;
-    const double u = u64_to_open01(rng_next_u64(rng));
-    if (f.st <= KS_H2) {
-        int hres = -1;
-        if (f.st == KS_H0) {
-            f.ha = u;
-            if (!(u < 0.5)) hres = 1; else f.st = KS_H1;
-        } else if (f.st == KS_H1) {
-            f.hb = u;
-            if (!(f.hb < f.ha)) hres = 0; else f.st = KS_H2;
+    uint64_t m = rng_next_u64(rng) >> 11;
+    m = m ? m : 1;  // u64_to_open01's clamp away from 0 (m < 2^53 always)
+    const bool is_h = f.st == KS_H, is_b0 = f.st == KS_B0, is_b1 = f.st == KS_B1;
+    // B's step cap (n > 4096) ends the run as a failed comparison would
+    const bool cont = (m < f.T) && !(is_b1 && f.bn > 4096);
+    f.zz = is_b0 ? m : f.zz;
+    if (cont) {
+        f.T = is_h ? m : (is_b0 ? f.bt : f.zz);
+        f.par ^= is_h ? 1 : 0;
+        f.bn += is_b1 ? 1 : 0;
+        f.st = is_h ? KS_H : (is_b0 ? KS_B1 : KS_B0);
+        return;
+    }
+    // the run ended: H reports parity-even, B reports n even
+    const bool ok = is_h ? (f.par == 0) : ((f.bn & 1) == 0);
+    bool restart = false;
+    int32_t next = KS_H;
+    if (is_h) {
+        if (!f.in_p) {  // G counts consecutive successes, then P needs k(k-1) of them
+            const int32_t k2 = f.k + (ok ? 1 : 0);
+            const bool g_done = !ok || k2 > 1024;
+            const int32_t pl = k2 * (k2 - 1);
+            f.k = k2;
+            f.p_left = pl;
+            f.in_p = g_done && pl != 0;
+            next = (g_done && pl == 0) ? KS_SIGN : KS_H;
         } else {
-            f.ha = u;
-            if (!(f.ha < f.hb)) hres = 1; else f.st = KS_H1;
-        }
-        if (hres >= 0) {
-            if (!f.in_p) {  // G: count successes
-                bool g_done = hres == 0;
-                if (hres == 1) {
-                    ++f.k;
-                    if (f.k > 1024) g_done = true;
-                }
-                if (g_done) {
-                    f.p_left = f.k * (f.k - 1);
-                    if (f.p_left == 0) f.st = KS_SIGN;
-                    else { f.in_p = true; f.st = KS_H0; }
-                } else {
-                    f.st = KS_H0;
-                }
-            } else if (hres == 1) {  // P: needs p_left successes
-                f.st = (--f.p_left == 0) ? KS_SIGN : KS_H0;
-            } else {
-                karney_restart(f);
-            }
+            const int32_t pl = f.p_left - 1;
+            f.p_left = pl;
+            restart = !ok;
+            next = pl == 0 ? KS_SIGN : KS_H;
         }
     } else {
-        int bres = -1;
-        if (f.st == KS_B0) {
-            f.zz = u;
-            if (!(f.zz < f.y)) bres = (f.bn % 2) == 0; else f.st = KS_B1;
-        } else {
-            if (!(u < f.bthr)) {
-                bres = (f.bn % 2) == 0;
-            } else {
-                f.y = f.zz;
-                if (f.bn > 4096) bres = (f.bn % 2) == 0;
-                else { ++f.bn; f.st = KS_B0; }
-            }
-        }
-        if (bres == 1) {
-            if (--f.b_left == 0) {
-                f.st = KS_DONE;
-            } else {
-                f.y = f.x;
-                f.bn = 0;
-                f.st = KS_B0;
-            }
-        } else if (bres == 0) {
-            karney_restart(f);
-        }
+        const int32_t bl = f.b_left - 1;
+        f.b_left = bl;
+        restart = !ok;
+        next = bl == 0 ? KS_DONE : KS_B0;
     }
+    if (restart) {
+        const int32_t it = f.iter + 1;
+        f.iter = it;
+        f.k = 0;
+        f.in_p = false;
+        next = it >= (1 << 16) ? KS_FALLBACK : KS_H;
+    }
+    f.st = next;
+    f.T = next == KS_H ? KARNEY_HALF : f.xt;  // a fresh H run, or B(k, x) starting over with y = x
+    f.par = 0;
+    f.bn = 0;
 }
 
 // the expensive transitions; call at wave-convergent service points
@@ -452,13 +453,20 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, ChaChaRng &rng) {
         const double x0 = (static_cast<double>(i0) - di0) / f.stddev;
         uint64_t j = w2 - __umul64hi(w2, f.magic) * f.cs;  // w2 % cs
         while (j >= f.cs) j -= f.cs;
-        f.x = x0 + static_cast<double>(static_cast<int64_t>(j)) / f.stddev;
-        if (!(f.x < 1.0) || (f.x == 0.0 && s < 0 && f.k == 0)) {
-            karney_restart(f);
+        const double x = x0 + static_cast<double>(static_cast<int64_t>(j)) / f.stddev;
+        if (!(x < 1.0) || (x == 0.0 && s < 0 && f.k == 0)) {
+            const int32_t it = f.iter + 1;
+            f.iter = it;
+            f.k = 0;
+            f.in_p = false;
+            f.st = it >= (1 << 16) ? KS_FALLBACK : KS_H;
+            f.T = KARNEY_HALF;
+            f.par = 0;
         } else {
             f.b_left = f.k + 1;
-            f.bthr = (2.0 * static_cast<double>(f.k) + f.x) / static_cast<double>(2 * f.k + 2);
-            f.y = f.x;
+            f.xt = karney_ticks(x);
+            f.bt = karney_ticks((2.0 * static_cast<double>(f.k) + x) / static_cast<double>(2 * f.k + 2));
+            f.T = f.xt;
             f.bn = 0;
             f.result = s * (i0 + static_cast<int64_t>(j));
             f.st = KS_B0;

@@ -61,42 +61,49 @@ __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict_
         dst[static_cast<size_t>(l) * N] = signed_to_residue_mu<W>(z, limbs[l].q, limbs[l].mu64);
 }
 
-// discrete Gaussian: persistent lanes (rng.h).  Lane `tid` of block b owns coefficients
-// b*256*per_lane + e*256 + tid, e < per_lane, each with its own stream (sub-key shared by all).
+// discrete Gaussian: persistent lanes (rng.h).  Block b owns coefficients [b*256*per_lane, +256*per_lane);
+// its lanes take them one at a time from a shared counter, each coefficient with its own stream
+// (sub-key shared by all).
 template <typename W>
 __global__ void __launch_bounds__(256) sample_gauss_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
-                                    size_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L, uint32_t N,
+                                    uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane) {
     __shared__ uint64_t ring[256 * RNG_RING_WORDS];
-    const size_t total = polys * N;
-    const size_t first = static_cast<size_t>(blockIdx.x) * 256u * per_lane + threadIdx.x;
+    __shared__ uint32_t next_e;
+    if (threadIdx.x == 0) next_e = 0;
+    __syncthreads();
+    const size_t total = polys << logN;  // polys < 2^32 (checked by the launcher)
+    const size_t N = static_cast<size_t>(1) << logN;
+    const size_t chunk_base = static_cast<size_t>(blockIdx.x) * 256u * per_lane;
+    const uint32_t chunk_len = static_cast<uint32_t>(std::min<size_t>(256u * static_cast<size_t>(per_lane), total - chunk_base));
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
     KarneyFsm f;
     f.st = KS_DONE;
-    uint32_t e = ~0u;  // nothing sampled yet
+    bool have = false;
     size_t idx = 0;
     for (uint32_t step = 0;; ++step) {
         if ((step & 3) == 0) {
-            if (f.st == KS_DONE) {
-                if (e != ~0u) {
-                    const size_t p = idx / N;
-                    W *dst = out + p * L * N + (idx - p * N);
-                    for (uint32_t l = 0; l < L; ++l)
-                        dst[static_cast<size_t>(l) * N] = signed_to_residue_mu<W>(f.result, limbs[l].q, limbs[l].mu64);
-                }
-                ++e;
-                idx = first + static_cast<size_t>(e) * 256u;
-                if (e < per_lane && idx < total) {
-                    const size_t p = idx / N;
-                    const size_t row = p / local_ncol, lcol = p - row * local_ncol;
-                    rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx - p * N) + 1);
-                    karney_begin(f, 0.0, sigma, div);
-                } else {
-                    f.st = KS_IDLE;
-                }
-            }
             if ((step & 7) == 0) {
+                if (f.st == KS_DONE) {  // write the finished coefficient, open the next one's stream
+                    if (have) {
+                        const size_t p = idx >> logN;
+                        W *dst = out + ((p * L) << logN) + (idx & (N - 1));
+                        for (uint32_t l = 0; l < L; ++l)
+                            dst[static_cast<size_t>(l) << logN] = signed_to_residue_mu<W>(f.result, limbs[l].q, limbs[l].mu64);
+                    }
+                    const uint32_t e = atomicAdd(&next_e, 1u);
+                    have = e < chunk_len;
+                    if (have) {
+                        idx = chunk_base + e;
+                        const uint32_t p = static_cast<uint32_t>(idx >> logN);
+                        const uint32_t row = p / local_ncol, lcol = p - row * local_ncol;
+                        rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx & (N - 1)) + 1);
+                        karney_begin(f, 0.0, sigma, div);
+                    } else {
+                        f.st = KS_IDLE;
+                    }
+                }
                 if (__all(f.st == KS_IDLE)) break;
                 if (f.st != KS_IDLE) rng_fill(rng);
             }
@@ -124,19 +131,21 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
     const uint32_t N = static_cast<uint32_t>(ctx->N);
     if (dist == GPU_MATRIX_DIST_GAUSS) {
         // enough lanes to fill the chip first, then up to 16 coefficients per lane
-        const size_t chip_lanes = 256u * 256u * 5u;
-        const uint32_t per_lane = sampler_per_lane(total, chip_lanes);
+        if (polys >> 32) return set_error("gpu_matrix_sample_distribution: too many polynomials");
+        const uint32_t per_lane = sampler_per_lane(
+            total, ctx->wide ? reinterpret_cast<const void *>(sample_gauss_kernel<uint64_t>)
+                             : reinterpret_cast<const void *>(sample_gauss_kernel<uint32_t>), ctx->device);
         const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
         const KarneyDivisor div = karney_divisor(sigma);
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
         if (ctx->wide)
             hipLaunchKernelGGL(sample_gauss_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
-                               L, N, sigma, div, key, per_lane);
+                               static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, static_cast<uint32_t>(out->cols),
+                               full_ncol, col_offset, L, ctx->logN, sigma, div, key, per_lane);
         else
             hipLaunchKernelGGL(sample_gauss_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               static_cast<uint32_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
-                               L, N, sigma, div, key, per_lane);
+                               static_cast<uint32_t *>(out->data), ctx->d_limbs, polys, static_cast<uint32_t>(out->cols),
+                               full_ncol, col_offset, L, ctx->logN, sigma, div, key, per_lane);
     } else {
         const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
         if (ctx->wide)

@@ -151,20 +151,45 @@ __global__ void gadget_keys_kernel(ChaChaKey *__restrict__ keys, uint32_t N, Gpu
     if (i < N) keys[i] = chacha_subkey(seed, static_cast<uint64_t>(i) + 1, kTagGadget);
 }
 
+// per-tower constants of the sampler: c_last = c_{dpt-1} of the tower's modulus digits, the width
+// sigma / c_last of the first Karney integer and its divisor
+struct GqTower {
+    double c_last, sd;
+    KarneyDivisor div;
+};
+
+__global__ void gq_tower_kernel(GqTower *__restrict__ towers, const LimbConst *__restrict__ limbs, uint32_t L,
+                                uint32_t dpt, uint32_t base_bits, double c) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L) return;
+    const uint64_t base = 1ull << base_bits;
+    const double base_f = static_cast<double>(base);
+    const double sigma = c / (base_f + 1.0);
+    const uint64_t qt = limbs[t].q;
+    double c_last = 0.0;
+    for (uint32_t d = 0; d < dpt; ++d)
+        c_last = (c_last + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
+    GqTower g;
+    g.c_last = c_last;
+    g.sd = sigma / c_last;
+    g.div = karney_divisor(g.sd);
+    towers[t] = g;
+}
+
 // Pass 1, fully convergent: the dpt normals every element draws first (words 0..2*dpt-1 of its
-// stream) and the centres a_d they imply; a_out is [dpt][total].
+// stream) and the centres a_d they imply.  a_out is [dpt][total]; the 8 - 2*dpt words of keystream
+// block 0 the normals did not use are handed to pass 2 in left_out ([8 - 2*dpt][total]).
 template <typename W, int MAXD>
-__global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict__ a_out, const W *__restrict__ src,
-                                       const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
-                                       size_t total, uint32_t L, uint32_t N, uint32_t dpt, uint32_t base_bits,
-                                       double c) {
+__global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict__ a_out, uint64_t *__restrict__ left_out,
+                                       const W *__restrict__ src, const LimbConst *__restrict__ limbs,
+                                       const ChaChaKey *__restrict__ keys, size_t total, uint32_t L, uint32_t logN,
+                                       uint32_t dpt, uint32_t base_bits, double c) {
     __shared__ uint64_t ring[256 * RNG_RING_WORDS];
     const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const uint32_t i = static_cast<uint32_t>(idx % N);
-    const size_t pt = idx / N;
-    const uint32_t t = static_cast<uint32_t>(pt % L);
-    const size_t p = pt / L;
+    const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
+    const uint32_t pt = static_cast<uint32_t>(idx >> logN);
+    const uint32_t p = pt / L, t = pt - p * L;
     const uint64_t qt = limbs[t].q;
     uint64_t value = static_cast<uint64_t>(src[idx]);
     if (value >= qt) value %= qt;
@@ -179,6 +204,7 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     double zf[MAXD];
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) zf[d] = d < (int)dpt ? sigma * rng_standard_normal(rng) : 0.0;
+    for (uint32_t w = 0; w < 8 - 2 * dpt; ++w) left_out[static_cast<size_t>(w) * total + idx] = rng_next_u64(rng);
     double prev_a = 0.0;
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) {
@@ -201,27 +227,34 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     }
 }
 
-// Pass 2: the dpt Karney integers of every element.  Lane `tid` of block b owns elements
-// b*256*per_lane + e*256 + tid.  ph = index of the integer in flight (0: z_last, 1+d: z_d).
+// Pass 2: the dpt Karney integers of every element.  Block b owns elements [b*256*per_lane,
+// +256*per_lane) and its lanes take them one at a time from a shared counter.
+// ph = index of the integer in flight (0: z_last, 1+d: z_d).
 template <typename W, int MAXD>
-__global__ void __launch_bounds__(256) gauss_samp_lanes_kernel(W *__restrict__ out, const W *__restrict__ src,
+__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(W *__restrict__ out, const W *__restrict__ src,
                                         const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
-                                        const double *__restrict__ a_in, size_t total, uint32_t src_cols, uint32_t L,
-                                        uint32_t N, uint32_t dpt, uint32_t base_bits, double c, size_t k,
-                                        KarneyDivisor div_sigma, uint32_t per_lane) {
+                                        const GqTower *__restrict__ towers, const double *__restrict__ a_in,
+                                        const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
+                                        uint32_t L, uint32_t logN, uint32_t dpt, uint32_t base_bits, double c,
+                                        uint32_t k, KarneyDivisor div_sigma, uint32_t per_lane) {
     __shared__ uint64_t ring[256 * RNG_RING_WORDS];
+    __shared__ uint32_t next_e;
+    if (threadIdx.x == 0) next_e = 0;
+    __syncthreads();
     const uint64_t base = 1ull << base_bits;
     const double base_f = static_cast<double>(base);
     const double sigma = c / (base_f + 1.0);
     const int last = static_cast<int>(dpt) - 1;
-    const size_t first = static_cast<size_t>(blockIdx.x) * 256u * per_lane + threadIdx.x;
+    const uint32_t nleft = 8 - 2 * dpt;
+    const size_t chunk_base = static_cast<size_t>(blockIdx.x) * 256u * per_lane;
+    const uint32_t chunk_len = static_cast<uint32_t>(std::min<size_t>(256u * static_cast<size_t>(per_lane), total - chunk_base));
 
     ChaChaRng rng;
     rng_init_keyed(rng, ring, ChaChaKey{}, 0, 0);
     KarneyFsm f;
     f.st = KS_DONE;
-    bool fin = true;
-    uint32_t e = ~0u, skip = 0, ph = 0;
+    bool fin = true, have = false;
+    uint32_t ph = 0;
     size_t idx = 0;
     uint64_t qt = 1, value = 0;
     double a[MAXD];
@@ -262,12 +295,11 @@ __global__ void __launch_bounds__(256) gauss_samp_lanes_kernel(W *__restrict__ o
             }
             if ((step & 7) == 0) {
                 if (f.st == KS_DONE && fin) {  // element complete: write its digits, take the next one
-                    if (e != ~0u) {
-                        const uint32_t i = static_cast<uint32_t>(idx % N);
-                        const size_t pt = idx / N;
-                        const uint32_t t = static_cast<uint32_t>(pt % L);
-                        const size_t p = pt / L;
-                        const size_t r = p / src_cols, col = p - r * src_cols;
+                    if (have) {
+                        const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
+                        const uint32_t pt = static_cast<uint32_t>(idx >> logN);
+                        const uint32_t p = pt / L, t = pt - p * L;
+                        const uint32_t r = p / src_cols, col = p - r * src_cols;
                         int64_t z_prev = 0;
 #pragma unroll
                         for (int d = 0; d < MAXD; ++d) {
@@ -281,49 +313,49 @@ __global__ void __launch_bounds__(256) gauss_samp_lanes_kernel(W *__restrict__ o
                                 else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
                                 else digit = md * z_last - z_prev + vd;
                                 z_prev = zd;
-                                const size_t orow = r * k + static_cast<size_t>(t) * dpt + d;
-                                const size_t opoly = orow * src_cols + col;
+                                const size_t orow = static_cast<size_t>(r) * k + t * dpt + d;
+                                W *dst = out + (((orow * src_cols + col) * L) << logN) + i;
                                 for (uint32_t l = 0; l < L; ++l)
-                                    out[(opoly * L + l) * N + i] = signed_to_residue_mu<W>(digit, limbs[l].q, limbs[l].mu64);
+                                    dst[static_cast<size_t>(l) << logN] = signed_to_residue_mu<W>(digit, limbs[l].q, limbs[l].mu64);
                             }
                         }
                     }
-                    ++e;
-                    idx = first + static_cast<size_t>(e) * 256u;
-                    if (e < per_lane && idx < total) {
-                        const uint32_t i = static_cast<uint32_t>(idx % N);
-                        const size_t pt = idx / N;
-                        const uint32_t t = static_cast<uint32_t>(pt % L);
-                        const size_t p = pt / L;
+                    const uint32_t e = atomicAdd(&next_e, 1u);
+                    have = e < chunk_len;
+                    if (have) {
+                        idx = chunk_base + e;
+                        const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
+                        const uint32_t pt = static_cast<uint32_t>(idx >> logN);
+                        const uint32_t p = pt / L, t = pt - p * L;
                         qt = limbs[t].q;
                         value = static_cast<uint64_t>(src[idx]);
                         if (value >= qt) value %= qt;
                         const ChaChaKey key = keys[i];
 #pragma unroll
                         for (int w = 0; w < 8; ++w) rng.state[4 + w] = key.w[w];
-                        rng_reopen(rng, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1);
-                        skip = 2 * dpt;  // the normals of pass 1
-                        double c_last = 0.0, a_last = 0.0;
+                        // block 0 went to pass 1: take its unused words, continue at block 1
+                        rng_reopen(rng, static_cast<uint64_t>(t) + 2, static_cast<uint64_t>(p) + 1);
+                        for (uint32_t w = 0; w < nleft; ++w)
+                            rng.ring[((rng.tail + w) & (RNG_RING_WORDS - 1)) * rng.ring_stride] = left_in[static_cast<size_t>(w) * total + idx];
+                        rng.tail += nleft;
+                        double a_last = 0.0;
 #pragma unroll
                         for (int d = 0; d < MAXD; ++d) {
                             if (d < (int)dpt) {
                                 a[d] = a_in[static_cast<size_t>(d) * total + idx];
-                                c_last = (c_last + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
                                 a_last = a[d];
                             }
                         }
                         ph = 0;
                         fin = false;
-                        const double sd = sigma / c_last;
-                        karney_begin(f, -a_last / c_last, sd, karney_divisor(sd));
+                        const GqTower tw = towers[t];
+                        karney_begin(f, -a_last / tw.c_last, tw.sd, tw.div);
                     } else {
                         f.st = KS_IDLE;
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
                 if (f.st != KS_IDLE) rng_fill(rng);
-                rng.head += skip;
-                skip = 0;
             }
             karney_heavy(f, rng);
         }
@@ -335,26 +367,35 @@ template <typename W, int MAXD>
 static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t total, uint32_t src_cols, uint32_t L,
                                    uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
     const uint32_t N = static_cast<uint32_t>(ctx->N);
-    void *keys = nullptr, *a_buf = nullptr;
+    if ((total >> ctx->logN) >> 32 || k >> 32) return set_error("gpu_matrix_gauss_samp_gq_arb_base: matrix too large");
+    void *keys = nullptr, *towers = nullptr, *a_buf = nullptr;  // [N] sub-keys | [L] towers | [8][total] words
     if (ctx_alloc(ctx, static_cast<size_t>(N) * sizeof(ChaChaKey), &keys) ||
-        ctx_alloc(ctx, total * dpt * sizeof(double), &a_buf)) {
+        ctx_alloc(ctx, static_cast<size_t>(L) * sizeof(GqTower), &towers) ||
+        ctx_alloc(ctx, total * 8 * sizeof(uint64_t), &a_buf)) {
         ctx_free(ctx, keys);
+        ctx_free(ctx, towers);
         return 1;
     }
+    double *a_words = static_cast<double *>(a_buf);
+    uint64_t *left_words = static_cast<uint64_t *>(a_buf) + total * dpt;
     hipLaunchKernelGGL(gadget_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream,
                        static_cast<ChaChaKey *>(keys), N, seed);
+    hipLaunchKernelGGL(gq_tower_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<GqTower *>(towers), ctx->d_limbs,
+                       L, dpt, base_bits, c);
     hipLaunchKernelGGL((gauss_samp_prep_kernel<W, MAXD>), dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
-                       ctx->stream, static_cast<double *>(a_buf), src, ctx->d_limbs,
-                       static_cast<const ChaChaKey *>(keys), total, L, N, dpt, base_bits, c);
-    const size_t chip_lanes = 256u * 256u * 4u;
-    const uint32_t per_lane = sampler_per_lane(total, chip_lanes);
+                       ctx->stream, a_words, left_words, src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys), total, L,
+                       ctx->logN, dpt, base_bits, c);
+    const uint32_t per_lane =
+        sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device);
     const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     hipLaunchKernelGGL((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream, out, src,
-                       ctx->d_limbs, static_cast<const ChaChaKey *>(keys), static_cast<const double *>(a_buf), total,
-                       src_cols, L, N, dpt, base_bits, c, k, karney_divisor(sigma), per_lane);
+                       ctx->d_limbs, static_cast<const ChaChaKey *>(keys), static_cast<const GqTower *>(towers), a_words,
+                       left_words, total, src_cols, L, ctx->logN, dpt, base_bits, c, static_cast<uint32_t>(k),
+                       karney_divisor(sigma), per_lane);
     const hipError_t err = hipGetLastError();
     ctx_free(ctx, keys);
+    ctx_free(ctx, towers);
     ctx_free(ctx, a_buf);
     HIP_TRY(err);
     return 0;
