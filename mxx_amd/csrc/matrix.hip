@@ -79,10 +79,7 @@ __global__ void scatter_i64_kernel(W *__restrict__ dst, const int64_t *__restric
     size_t poly = idx / N;
     uint32_t i = static_cast<uint32_t>(idx - poly * N);
     int64_t v = vals[idx];
-    for (uint32_t l = 0; l < L; ++l) {
-        W q = static_cast<W>(limbs[l].q);
-        dst[(poly * L + l) * N + i] = signed_to_residue<W>(v, q);
-    }
+    for (uint32_t l = 0; l < L; ++l) dst[(poly * L + l) * N + i] = signed_to_residue_mu<W>(v, limbs[l].q, limbs[l].mu64);
 }
 
 // ---- helpers ---------------------------------------------------------------------------

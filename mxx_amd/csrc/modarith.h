@@ -96,15 +96,15 @@ __device__ __forceinline__ W signed_to_residue(int64_t v, W q) {
 // same value as signed_to_residue without the 64-bit `%` (no hardware divider): mu64 = floor(2^64/q)
 template <typename W>
 __device__ __forceinline__ W signed_to_residue_mu(int64_t v, uint64_t q, uint64_t mu64) {
+    const int64_t sq = static_cast<int64_t>(q);  // q < 2^62
+    if (v > -sq && v < sq) return static_cast<W>(v < 0 ? v + sq : v);  // digits, small Gaussians
     const uint64_t mag = v >= 0 ? static_cast<uint64_t>(v) : static_cast<uint64_t>(-(v + 1)) + 1;
-    uint64_t r = mag;
-    if (mag >= q) {
-        if ((mag >> 32) == 0)  // quotient estimate from the top word of mu64 alone
-            r = mag - static_cast<uint64_t>(__umulhi(static_cast<uint32_t>(mag), static_cast<uint32_t>(mu64 >> 32))) * q;
-        else
-            r = mag - __umul64hi(mag, mu64) * q;
-        while (r >= q) r -= q;  // either estimate is at most 3 short
-    }
+    uint64_t r;
+    if ((mag >> 32) == 0)  // quotient estimate from the top word of mu64 alone
+        r = mag - static_cast<uint64_t>(__umulhi(static_cast<uint32_t>(mag), static_cast<uint32_t>(mu64 >> 32))) * q;
+    else
+        r = mag - __umul64hi(mag, mu64) * q;
+    while (r >= q) r -= q;  // either estimate is at most 3 short
     return static_cast<W>((v >= 0 || r == 0) ? r : q - r);
 }
 

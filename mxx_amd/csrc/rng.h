@@ -47,8 +47,11 @@ __host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return 
     a += b; d ^= a; d = rotl32(d, 8);  \
     c += d; b ^= c; b = rotl32(b, 7);
 
+// UNROLL = 10 removes the register shuffling a rolled loop needs inside large kernels (about a
+// third of the block cost there); the cold uses keep the rolled loop
+template <int UNROLL = 1>
 __host__ __device__ __forceinline__ void chacha_rounds(uint32_t (&x)[16]) {
-#pragma unroll 1
+#pragma unroll UNROLL
     for (int i = 0; i < 10; ++i) {
         CHACHA_QR(x[0], x[4], x[8], x[12])
         CHACHA_QR(x[1], x[5], x[9], x[13])
@@ -119,12 +122,13 @@ __device__ __forceinline__ uint32_t rng_avail(const ChaChaRng &rng) { return rng
 
 // Checkpoint: guarantees >= 8 words are available.  Call at wave-convergent points, at least
 // once per 8 draws.
+template <int UNROLL = 1>
 __device__ __forceinline__ void rng_fill(ChaChaRng &rng) {
     if (rng.tail - rng.head < 8) {
         uint32_t x[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) x[i] = rng.state[i];
-        chacha_rounds(x);
+        chacha_rounds<UNROLL>(x);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t lo = x[2 * i] + rng.state[2 * i], hi = x[2 * i + 1] + rng.state[2 * i + 1];

@@ -63,10 +63,11 @@ __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict_
 
 // discrete Gaussian: persistent lanes (rng.h).  Block b owns coefficients [b*256*per_lane, +256*per_lane);
 // its lanes take them one at a time from a shared counter, each coefficient with its own stream
-// (sub-key shared by all).
-template <typename W>
-__global__ void __launch_bounds__(256) sample_gauss_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
-                                    uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L, uint32_t logN,
+// (sub-key shared by all).  Lanes finish at different times, so a lane's store is a lone 8 bytes:
+// it goes to a compact int64 staging array ([poly][N]) that a coalesced pass expands into the L
+// residues per coefficient (storing the residues from here cost a 32-byte HBM write per limb).
+__global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
+                                    uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane) {
     __shared__ uint64_t ring[256 * RNG_RING_WORDS];
     __shared__ uint32_t next_e;
@@ -86,12 +87,7 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(W *__restrict__ out, 
         if ((step & 3) == 0) {
             if ((step & 7) == 0) {
                 if (f.st == KS_DONE) {  // write the finished coefficient, open the next one's stream
-                    if (have) {
-                        const size_t p = idx >> logN;
-                        W *dst = out + ((p * L) << logN) + (idx & (N - 1));
-                        for (uint32_t l = 0; l < L; ++l)
-                            dst[static_cast<size_t>(l) << logN] = signed_to_residue_mu<W>(f.result, limbs[l].q, limbs[l].mu64);
-                    }
+                    if (have) stage[idx] = f.result;
                     const uint32_t e = atomicAdd(&next_e, 1u);
                     have = e < chunk_len;
                     if (have) {
@@ -105,7 +101,7 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(W *__restrict__ out, 
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                if (f.st != KS_IDLE) rng_fill(rng);
+                if (f.st != KS_IDLE) rng_fill<10>(rng);
             }
             karney_heavy(f, rng);
         }
@@ -132,20 +128,19 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
     if (dist == GPU_MATRIX_DIST_GAUSS) {
         // enough lanes to fill the chip first, then up to 16 coefficients per lane
         if (polys >> 32) return set_error("gpu_matrix_sample_distribution: too many polynomials");
-        const uint32_t per_lane = sampler_per_lane(
-            total, ctx->wide ? reinterpret_cast<const void *>(sample_gauss_kernel<uint64_t>)
-                             : reinterpret_cast<const void *>(sample_gauss_kernel<uint32_t>), ctx->device);
+        const uint32_t per_lane = sampler_per_lane(total, reinterpret_cast<const void *>(sample_gauss_kernel), ctx->device);
         const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
         const KarneyDivisor div = karney_divisor(sigma);
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
-        if (ctx->wide)
-            hipLaunchKernelGGL(sample_gauss_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, static_cast<uint32_t>(out->cols),
-                               full_ncol, col_offset, L, ctx->logN, sigma, div, key, per_lane);
-        else
-            hipLaunchKernelGGL(sample_gauss_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               static_cast<uint32_t *>(out->data), ctx->d_limbs, polys, static_cast<uint32_t>(out->cols),
-                               full_ncol, col_offset, L, ctx->logN, sigma, div, key, per_lane);
+        void *stage = nullptr;
+        if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
+        hipLaunchKernelGGL(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
+                           static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane);
+        const hipError_t err = hipGetLastError();
+        const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
+        ctx_free(ctx, stage);
+        HIP_TRY(err);
+        if (rc) return rc;
     } else {
         const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
         if (ctx->wide)

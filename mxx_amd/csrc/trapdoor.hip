@@ -231,12 +231,12 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 // +256*per_lane) and its lanes take them one at a time from a shared counter.
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
 template <typename W, int MAXD>
-__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(W *__restrict__ out, const W *__restrict__ src,
+__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ src,
                                         const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
                                         uint32_t L, uint32_t logN, uint32_t dpt, uint32_t base_bits, double c,
-                                        uint32_t k, KarneyDivisor div_sigma, uint32_t per_lane) {
+                                        KarneyDivisor div_sigma, uint32_t per_lane) {
     __shared__ uint64_t ring[256 * RNG_RING_WORDS];
     __shared__ uint32_t next_e;
     if (threadIdx.x == 0) next_e = 0;
@@ -296,10 +296,6 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(W *__restrict_
             if ((step & 7) == 0) {
                 if (f.st == KS_DONE && fin) {  // element complete: write its digits, take the next one
                     if (have) {
-                        const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
-                        const uint32_t pt = static_cast<uint32_t>(idx >> logN);
-                        const uint32_t p = pt / L, t = pt - p * L;
-                        const uint32_t r = p / src_cols, col = p - r * src_cols;
                         int64_t z_prev = 0;
 #pragma unroll
                         for (int d = 0; d < MAXD; ++d) {
@@ -313,10 +309,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(W *__restrict_
                                 else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
                                 else digit = md * z_last - z_prev + vd;
                                 z_prev = zd;
-                                const size_t orow = static_cast<size_t>(r) * k + t * dpt + d;
-                                W *dst = out + (((orow * src_cols + col) * L) << logN) + i;
-                                for (uint32_t l = 0; l < L; ++l)
-                                    dst[static_cast<size_t>(l) << logN] = signed_to_residue_mu<W>(digit, limbs[l].q, limbs[l].mu64);
+                                stage[idx * dpt + d] = digit;
                             }
                         }
                     }
@@ -355,11 +348,33 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(W *__restrict_
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                if (f.st != KS_IDLE) rng_fill(rng);
+                if (f.st != KS_IDLE) rng_fill<10>(rng);
             }
             karney_heavy(f, rng);
         }
         karney_light(f, rng);
+    }
+}
+
+// Pass 3, coalesced: digit (p, t, i, d) -> residues in every limb of output row r*k + t*dpt + d.
+// (Pass 2's lanes finish at different times; storing L residues per digit from there made every
+// store a lone 32-byte HBM write - 6x the algorithmic bytes.)
+template <typename W>
+__global__ void __launch_bounds__(256) gauss_samp_expand_kernel(W *__restrict__ out, const int64_t *__restrict__ stage,
+                                         const LimbConst *__restrict__ limbs, size_t total, uint32_t src_cols, uint32_t L,
+                                         uint32_t logN, uint32_t dpt, uint32_t k) {
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
+    const uint32_t pt = static_cast<uint32_t>(idx >> logN);
+    const uint32_t p = pt / L, t = pt - p * L;
+    const uint32_t r = p / src_cols, col = p - r * src_cols;
+    for (uint32_t d = 0; d < dpt; ++d) {
+        const int64_t digit = stage[idx * dpt + d];
+        const size_t orow = static_cast<size_t>(r) * k + t * dpt + d;
+        W *dst = out + (((orow * src_cols + col) * L) << logN) + i;
+        for (uint32_t l = 0; l < L; ++l)
+            dst[static_cast<size_t>(l) << logN] = signed_to_residue_mu<W>(digit, limbs[l].q, limbs[l].mu64);
     }
 }
 
@@ -368,12 +383,14 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
                                    uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
     const uint32_t N = static_cast<uint32_t>(ctx->N);
     if ((total >> ctx->logN) >> 32 || k >> 32) return set_error("gpu_matrix_gauss_samp_gq_arb_base: matrix too large");
-    void *keys = nullptr, *towers = nullptr, *a_buf = nullptr;  // [N] sub-keys | [L] towers | [8][total] words
+    // [N] sub-keys | [L] towers | [8][total] words between passes 1 and 2 | [total][dpt] digits
+    void *keys = nullptr, *towers = nullptr, *a_buf = nullptr, *stage = nullptr;
     if (ctx_alloc(ctx, static_cast<size_t>(N) * sizeof(ChaChaKey), &keys) ||
         ctx_alloc(ctx, static_cast<size_t>(L) * sizeof(GqTower), &towers) ||
-        ctx_alloc(ctx, total * 8 * sizeof(uint64_t), &a_buf)) {
+        ctx_alloc(ctx, total * 8 * sizeof(uint64_t), &a_buf) || ctx_alloc(ctx, total * dpt * sizeof(int64_t), &stage)) {
         ctx_free(ctx, keys);
         ctx_free(ctx, towers);
+        ctx_free(ctx, a_buf);
         return 1;
     }
     double *a_words = static_cast<double *>(a_buf);
@@ -389,14 +406,18 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
         sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device);
     const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
-    hipLaunchKernelGGL((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream, out, src,
-                       ctx->d_limbs, static_cast<const ChaChaKey *>(keys), static_cast<const GqTower *>(towers), a_words,
-                       left_words, total, src_cols, L, ctx->logN, dpt, base_bits, c, static_cast<uint32_t>(k),
-                       karney_divisor(sigma), per_lane);
+    hipLaunchKernelGGL((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
+                       static_cast<int64_t *>(stage), src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys),
+                       static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
+                       base_bits, c, karney_divisor(sigma), per_lane);
+    hipLaunchKernelGGL(gauss_samp_expand_kernel<W>, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       ctx->stream, out, static_cast<const int64_t *>(stage), ctx->d_limbs, total, src_cols, L, ctx->logN,
+                       dpt, static_cast<uint32_t>(k));
     const hipError_t err = hipGetLastError();
     ctx_free(ctx, keys);
     ctx_free(ctx, towers);
     ctx_free(ctx, a_buf);
+    ctx_free(ctx, stage);
     HIP_TRY(err);
     return 0;
 }
