@@ -92,6 +92,7 @@ struct GpuP1CovarianceCache {
     double sigma = 0, s = 0, dgg_stddev = 0;
     double *sqrt_var = nullptr;      // [coeff][row]
     double *update_coeff = nullptr;  // [coeff][sampled_row][updated_row]
+    void *karney_div = nullptr;      // [coeff][row] KarneyDivisor of sqrt_var (rng.h)
 };
 
 // ---- error plumbing ---------------------------------------------------------

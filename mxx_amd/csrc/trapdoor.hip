@@ -590,6 +590,90 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
     }
 }
 
+__global__ void p1_divisor_kernel(KarneyDivisor *__restrict__ div, const double *__restrict__ sqrt_var, size_t count) {
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx < count) div[idx] = karney_divisor(sqrt_var[idx]);
+}
+
+// persistent-lane form for m <= 4 (rng.h): element = (column, coefficient), m dependent Karney
+// integers each (rows m-1 .. 0); integers go to the int64 staging array [row][col][N]
+template <typename W, int MAXM>
+__global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ tp2,
+                                       const double *__restrict__ sqrt_var_base, const double *__restrict__ update_base,
+                                       const KarneyDivisor *__restrict__ div_base, uint32_t m, uint32_t cols, uint32_t L,
+                                       uint32_t logN, uint64_t q0, double c_scale, ChaChaKey key, size_t total,
+                                       uint32_t per_lane) {
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
+    __shared__ uint32_t next_e;
+    if (threadIdx.x == 0) next_e = 0;
+    __syncthreads();
+    const size_t chunk_base = static_cast<size_t>(blockIdx.x) * 256u * per_lane;
+    const uint32_t chunk_len = static_cast<uint32_t>(std::min<size_t>(256u * static_cast<size_t>(per_lane), total - chunk_base));
+    ChaChaRng rng;
+    rng_init_keyed(rng, ring, key, 0, 0);
+    KarneyFsm f;
+    f.st = KS_DONE;
+    bool fin = true, have = false;
+    uint32_t t = 0, col = 0, i = 0;
+    double mean[MAXM], mu = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXM; ++r) mean[r] = 0.0;
+
+    for (uint32_t step = 0;; ++step) {
+        if ((step & 3) == 0) {
+            if (f.st == KS_DONE && !fin) {  // the integer of row t is ready
+                const int64_t z = f.result;
+                stage[((static_cast<size_t>(t) * cols + col) << logN) + i] = z;
+                const double delta = static_cast<double>(z) - mu;
+                const double *upd = update_base + (static_cast<size_t>(i) * m + t) * m;
+#pragma unroll
+                for (int r = 0; r < MAXM; ++r)
+                    if (r < (int)t) mean[r] += upd[r] * delta;
+                if (t == 0) {
+                    fin = true;
+                } else {
+                    --t;
+#pragma unroll
+                    for (int r = 0; r < MAXM; ++r)
+                        if (r == (int)t) mu = mean[r];
+                    const size_t sv = static_cast<size_t>(i) * m + t;
+                    karney_begin(f, mu, sqrt_var_base[sv], div_base[sv]);
+                }
+            }
+            if ((step & 7) == 0) {
+                if (f.st == KS_DONE && fin) {
+                    const uint32_t e = atomicAdd(&next_e, 1u);
+                    have = e < chunk_len;
+                    if (have) {
+                        const size_t idx = chunk_base + e;
+                        col = static_cast<uint32_t>(idx >> logN);
+                        i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
+#pragma unroll
+                        for (int r = 0; r < MAXM; ++r)
+                            if (r < (int)m)
+                                mean[r] = c_scale * static_cast<double>(centered_residue(
+                                                        tp2[(((static_cast<size_t>(r) * cols + col) * L) << logN) + i], q0));
+                        rng_reopen(rng, static_cast<uint64_t>(col) + 1, static_cast<uint64_t>(i) + 1);
+                        t = m - 1;
+#pragma unroll
+                        for (int r = 0; r < MAXM; ++r)
+                            if (r == (int)t) mu = mean[r];
+                        fin = false;
+                        const size_t sv = static_cast<size_t>(i) * m + t;
+                        karney_begin(f, mu, sqrt_var_base[sv], div_base[sv]);
+                    } else {
+                        f.st = KS_IDLE;
+                    }
+                }
+                if (__all(f.st == KS_IDLE)) break;
+                if (f.st != KS_IDLE) rng_fill<10>(rng);
+            }
+            karney_heavy(f, rng);
+        }
+        karney_light(f, rng);
+    }
+}
+
 static int check_p1_inputs(const GpuMatrix *a, const GpuMatrix *b, const GpuMatrix *d, double sigma, double s,
                            double dgg_stddev, const char *who) {
     if (!a || !b || !d) return set_error(std::string("invalid ") + who + " arguments");
@@ -631,9 +715,9 @@ extern "C" int gpu_matrix_create_p1_covariance_cache(const GpuMatrix *a_mat, con
         delete cache;
         return 1;
     }
-    void *cov_ws = nullptr, *sv = nullptr, *uc = nullptr;
+    void *cov_ws = nullptr, *sv = nullptr, *uc = nullptr, *kd = nullptr;
     if (ctx_alloc(ctx, n * m * m * sizeof(double), &cov_ws) || ctx_alloc(ctx, n * m * sizeof(double), &sv) ||
-        ctx_alloc(ctx, n * m * m * sizeof(double), &uc)) {
+        ctx_alloc(ctx, n * m * m * sizeof(double), &uc) || ctx_alloc(ctx, n * m * sizeof(KarneyDivisor), &kd)) {
         ctx_free(ctx, cov_ws);
         ctx_free(ctx, sv);
         ctx_free(ctx, uc);
@@ -642,6 +726,7 @@ extern "C" int gpu_matrix_create_p1_covariance_cache(const GpuMatrix *a_mat, con
     }
     cache->sqrt_var = static_cast<double *>(sv);
     cache->update_coeff = static_cast<double *>(uc);
+    cache->karney_div = kd;
     HIP_TRY(hipMemsetAsync(uc, 0, n * m * m * sizeof(double), ctx->stream));
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(a_mat));
     const unsigned blocks = static_cast<unsigned>((n + 127) / 128);
@@ -655,6 +740,8 @@ extern "C" int gpu_matrix_create_p1_covariance_cache(const GpuMatrix *a_mat, con
                            static_cast<const uint32_t *>(a_mat->data), static_cast<const uint32_t *>(b_mat->data),
                            static_cast<const uint32_t *>(d_mat->data), (uint32_t)d, L, (uint32_t)n, ctx->moduli[0],
                            sigma, s, dgg_stddev, static_cast<double *>(cov_ws), cache->sqrt_var, cache->update_coeff);
+    hipLaunchKernelGGL(p1_divisor_kernel, dim3(static_cast<unsigned>((n * m + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<KarneyDivisor *>(kd), cache->sqrt_var, n * m);
     hipError_t e = hipGetLastError();
     ctx_free(ctx, cov_ws);
     if (e != hipSuccess) {
@@ -672,6 +759,7 @@ extern "C" void gpu_matrix_destroy_p1_covariance_cache(GpuP1CovarianceCache *cac
         (void)hipSetDevice(cache->ctx->device);
         ctx_free(cache->ctx, cache->sqrt_var);
         ctx_free(cache->ctx, cache->update_coeff);
+        ctx_free(cache->ctx, cache->karney_div);
     }
     delete cache;
 }
@@ -699,6 +787,40 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
     if (ctx_activate(ctx)) return 1;
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(out)), N = static_cast<uint32_t>(ctx->N);
     const size_t total = cols * static_cast<size_t>(N);
+    // MXX_HIP_P1=simple keeps the one-thread-per-element kernel for every m (A/B runs, tests)
+    const char *mode = std::getenv("MXX_HIP_P1");
+    if (m <= 4 && !(mode && mode[0] == 's')) {
+        void *stage = nullptr;
+        if (ctx_alloc(ctx, total * m * sizeof(int64_t), &stage)) return 1;
+        const ChaChaKey key = chacha_subkey(seed, 0, kTagP1);
+#define LAUNCH_P1L(WT, MAXM)                                                                                      \
+    do {                                                                                                          \
+        const uint32_t per_lane =                                                                                 \
+            sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM>), ctx->device); \
+        const unsigned lblocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));        \
+        hipLaunchKernelGGL((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(256), 0, ctx->stream,          \
+                           static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,    \
+                           cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m, \
+                           (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane);          \
+    } while (0)
+        if (ctx->wide) {
+            if (m <= 2) LAUNCH_P1L(uint64_t, 2);
+            else LAUNCH_P1L(uint64_t, 4);
+        } else {
+            if (m <= 2) LAUNCH_P1L(uint32_t, 2);
+            else LAUNCH_P1L(uint32_t, 4);
+        }
+#undef LAUNCH_P1L
+        const hipError_t le = hipGetLastError();
+        int lrc = le == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
+        ctx_free(ctx, stage);
+        if (le != hipSuccess) return set_error(le, "p1_sample_lanes_kernel");
+        if (lrc) return lrc;
+        lrc = launch_ntt(ctx, out->data, matrix_polys(out) * L, static_cast<int>(L), false);
+        if (lrc) return lrc;
+        out->format = GPU_POLY_FORMAT_EVAL;
+        return 0;
+    }
     const unsigned blocks = static_cast<unsigned>((total + 127) / 128);
     void *mean_ws = nullptr;
     if (m > 8 && ctx_alloc(ctx, total * m * sizeof(double), &mean_ws)) return 1;

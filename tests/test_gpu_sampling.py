@@ -136,7 +136,10 @@ def test_gauss_samp_gq_statistically_matches_oracle(gpu, oracle):
 
 
 @pytest.mark.parametrize("d,n,bits", [(1, 64, 24), (2, 32, 24), (1, 32, 51), (5, 16, 24)])
-def test_p1_sampler_bit_exact(gpu, oracle, d, n, bits):
+@pytest.mark.parametrize("per_lane", ["", "3"])
+def test_p1_sampler_bit_exact(gpu, oracle, monkeypatch, per_lane, d, n, bits):
+    if per_lane:  # several elements per lane in the persistent-lane form (m <= 4)
+        monkeypatch.setenv("MXX_HIP_SAMPLER_PER_LANE", per_lane)
     depth, base = 2, 12 if bits == 24 else 17
     p = make_params(gpu, oracle, n, depth, bits, base)
     moduli = p.moduli()
