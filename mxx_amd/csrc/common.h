@@ -127,6 +127,8 @@ int matrix_check_same_shape(const GpuMatrix *a, const GpuMatrix *b, const char *
 int launch_ntt(GpuContext *ctx, void *data, size_t vectors, int limbs_per_poly, bool inverse);
 // tuned LDS kernels (ntt_lds_u32.hip / ntt_lds_u64.hip); return -1 when no tuned kernel covers logN
 int launch_ntt_lds_u32(GpuContext *ctx, uint32_t *data, size_t vectors, uint32_t L, bool inverse);
+int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff, size_t out_vectors, uint32_t L,
+                          uint32_t src_cols, uint32_t towers, uint32_t dpt, uint32_t base_bits, size_t k);
 int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t L, bool inverse);
 int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
 int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,

@@ -34,28 +34,25 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename W>
-__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
-    fwd_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
-               uint32_t L) {
+// forward transform of one vector: `load(e)` supplies coefficient e (natural order), the result
+// (canonical residues, bit-reversed order) goes to g
+template <typename W, typename Load>
+__device__ __forceinline__ void fwd_body(W *__restrict__ g, const Load &load, const TwPair<W> *__restrict__ tw_all,
+                                         const LimbConst &lc, uint32_t limb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *xs = reinterpret_cast<W *>(smem);  // [2][8][BLK_PAD]
     typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
     constexpr int VN = 16 / sizeof(W);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t vec = blockIdx.x;
-    const uint32_t limb = static_cast<uint32_t>(vec % L);
-    const LimbConst lc = limbs[limb];
     const W q = static_cast<W>(lc.q), twoq = q + q;
     const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
     const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
-    W *g = data + vec * N;
 
     // stages 0..4 in registers: element tid of each of the 32 blocks
     W h[R0];
 #pragma unroll
-    for (int u = 0; u < R0; ++u) h[u] = g[tid + T * u];
+    for (int u = 0; u < R0; ++u) h[u] = load(tid + T * u);
     ct_network_lazy<W, 5>(h, tw, 0, 0, q, twoq);
 
 #pragma unroll
@@ -100,6 +97,68 @@ __global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
         // the other buffer is used next; this one is rewritten two groups later, behind the
         // next group's barrier
     }
+}
+
+template <typename W>
+struct LoadVector {
+    const W *g;
+    __device__ __forceinline__ W operator()(uint32_t e) const { return g[e]; }
+};
+
+template <typename W>
+__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
+    fwd_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+               uint32_t L) {
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    W *g = data + vec * N;
+    fwd_body<W>(g, LoadVector<W>{g}, tw_all, limbs[limb], limb);
+}
+
+// Gadget decomposition fused into the transform's load (decompose.hip): output vector
+// (orow, col, limb) with orow = r*k + t*dpt + d is the NTT mod q_limb of the polynomial whose
+// coefficients are digit d (shift, mask) of the tower-t residues of source entry (r, col).  The
+// k-times larger digit matrix is written once, already in EVAL form, and never re-read.
+template <typename W>
+struct LoadDigit {
+    const W *src;  // coefficient-domain source vector (entry, tower)
+    uint32_t shift;
+    W mask, q;
+    bool reduce;  // wave-uniform: a digit can reach q (base wider than this limb)
+    __device__ __forceinline__ W operator()(uint32_t e) const {
+        const W digit = (src[e] >> shift) & mask;
+        return reduce ? digit % q : digit;
+    }
+};
+
+template <typename W>
+__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
+    fwd_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
+                      const LimbConst *__restrict__ limbs, uint32_t L, uint32_t src_cols, uint32_t towers, uint32_t dpt,
+                      uint32_t base_bits, uint32_t k) {
+    const size_t vec = blockIdx.x;  // (orow * src_cols + col) * L + limb
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const size_t opoly = vec / L;
+    const uint32_t col = static_cast<uint32_t>(opoly % src_cols);
+    const size_t orow = opoly / src_cols;
+    const size_t r = orow / k;
+    const uint32_t td = static_cast<uint32_t>(orow - r * k);
+    const uint32_t t = td / dpt, d = td - t * dpt;
+    const LimbConst lc = limbs[limb];
+    const uint32_t src_bits = limbs[t].kbits, shift = d * base_bits;
+    LoadDigit<W> load;
+    load.src = coeff + ((r * src_cols + col) * L + t) * N;
+    load.shift = shift < 8 * sizeof(W) ? shift : 0;
+    load.mask = 0;
+    if (shift < src_bits && shift < 8 * sizeof(W)) {
+        const uint32_t rem = src_bits - shift;
+        const uint32_t db = base_bits < rem ? base_bits : rem;
+        load.mask = db >= 8 * sizeof(W) ? static_cast<W>(~static_cast<W>(0)) : static_cast<W>((static_cast<W>(1) << db) - 1);
+    }
+    load.q = static_cast<W>(lc.q);
+    load.reduce = load.mask >= load.q;
+    (void)towers;
+    fwd_body<W>(out + vec * N, load, tw_all, lc, limb);
 }
 
 template <typename W>

@@ -267,6 +267,27 @@ def test_decompose_and_gadget(gpu, oracle, n, depth, bits, base):
     assert np.array_equal(sd.to_coeff_rns(), oracle.decompose(M, moduli, base, small=True))
 
 
+@pytest.mark.parametrize("depth,bits,base", [(3, 24, 12), (2, 24, 7), (2, 20, 20)])
+def test_decompose_fused_with_ntt_at_2_14(gpu, oracle, monkeypatch, depth, bits, base):
+    """n = 2^14 takes the fused digit + forward-NTT kernel (ntt14.h); it must give the bits of the
+    two-step path and of the CPU restatement (digit layout, last-digit mask, small variant)."""
+    n = 16384
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    M = rand_matrix(oracle, 41, 2, 2, moduli, n)
+    gm = gpu.GpuDCRTPolyMatrix.from_rns(p, M, False)
+    want = oracle.matrix_ntt(oracle.decompose(M, moduli, base), moduli)
+    fused = gm.decompose()
+    assert fused.is_ntt and np.array_equal(fused.to_rns(), want)
+    assert gm.ensure_eval().decompose() == fused  # EVAL source: private INTT copy feeds the fused kernel
+    small = gm.small_decompose()
+    assert np.array_equal(small.to_rns(), oracle.matrix_ntt(oracle.decompose(M, moduli, base, small=True), moduli))
+    monkeypatch.setenv("MXX_HIP_DECOMPOSE_FUSED", "0")
+    assert gm.decompose() == fused and gm.small_decompose() == small
+    G = gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 2)
+    assert G * fused == gm.ensure_eval()
+
+
 def test_small_decomposed_identity_chunk(gpu, oracle):
     """chunked == full (gpu_dcrt_poly.rs:2225-2334)."""
     n, base = 16, 4
