@@ -37,7 +37,7 @@ __device__ __forceinline__ void wave_sync() {
 // forward transform of one vector: `load(e)` supplies coefficient e (natural order), the result
 // (canonical residues, bit-reversed order) goes to g
 template <typename W, typename Load>
-__device__ __forceinline__ void fwd_body(W *__restrict__ g, const Load &load, const TwPair<W> *__restrict__ tw_all,
+__device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> *__restrict__ tw_all,
                                          const LimbConst &lc, uint32_t limb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *xs = reinterpret_cast<W *>(smem);  // [2][8][BLK_PAD]
@@ -106,13 +106,14 @@ struct LoadVector {
 };
 
 template <typename W>
-__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
+__global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                uint32_t L) {
     const size_t vec = blockIdx.x;
     const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
     W *g = data + vec * N;
-    fwd_body<W>(g, LoadVector<W>{g}, tw_all, limbs[limb], limb);
+    fwd_body<W>(g, LoadVector<W>{g}, tw_all, lc, limb);
 }
 
 // Gadget decomposition fused into the transform's load (decompose.hip): output vector
@@ -132,7 +133,7 @@ struct LoadDigit {
 };
 
 template <typename W>
-__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
+__global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
                       const LimbConst *__restrict__ limbs, uint32_t L, uint32_t src_cols, uint32_t towers, uint32_t dpt,
                       uint32_t base_bits, uint32_t k) {
