@@ -196,7 +196,7 @@ def main():
 
         units_per_step = r * k * c
         metric, unit = "dcrt_ring_ops_per_s", "ring-ops/s"
-        kernel_name = "matmul_kernel<uint32_t,...> (R_q matrix product, EVAL)"
+        kernel_name = "matmul_kernel<uint32_t,...> / mmdma::kernel_u32 (R_q matrix product, EVAL)"
         algo_bytes = float(r * k + k * c + r * c) * n * L * word
         workload_desc = f"{wl.upper()}: n=2^14, L={L} (24-bit), ({r}x{k})*({k}x{c}); 1 ring-op = one R_q multiply-accumulate"
     else:  # m3a

@@ -370,10 +370,15 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
         return launch_matmul_cfg<uint64_t, 1, 4, 1>(out, lhs, rhs);
     }
     {
-        // MXX_HIP_MATMUL_PATH = reg | lds forces a kernel family (tests cover both)
+        // MXX_HIP_MATMUL_PATH = reg | lds | dma forces a kernel family (tests cover all)
         const char *force = std::getenv("MXX_HIP_MATMUL_PATH");
         const bool lds_ok = N >= 64 && (N % 64) == 0;
-        const bool want_lds = force ? (force[0] == 'l') : (rows >= 8 && cols >= 8);
+        const bool want_dma = force ? (force[0] == 'd') : (rows >= 32 && cols >= 16);
+        if (want_dma) {
+            const int rc = launch_matmul_dma_u32(out, lhs, rhs);
+            if (rc >= 0) return rc;
+        }
+        const bool want_lds = force ? (force[0] == 'l' || force[0] == 'd') : (rows >= 8 && cols >= 8);
         if (lds_ok && want_lds) return launch_matmul_lds_u32(out, lhs, rhs);
     }
     if (N >= 4) {

@@ -1,0 +1,245 @@
+#include <atomic>
+// matmul_dma.hip — polynomial-matrix product for fat shapes (u32 words), operands streamed
+// global -> LDS without passing through registers, three stages deep.
+//
+// Same mapping as matmul_lds_kernel_u32 (arith.hip): lanes = 64 consecutive evaluation slots,
+// a workgroup owns a tile of C for those slots, 64-bit lazy accumulators.  What differs is how
+// operands arrive.  There, every wave loads the next K-chunk into 32 registers at the top of an
+// iteration and stores it to LDS at the bottom: one chunk (32 KB per workgroup) in flight, issued
+// one MAC phase ahead - less than the HBM latency for the 25-30 % of panel reads that are
+// compulsory L2 misses, so the VALU sits idle ~45 % of the time (profiles/r01_pmc_sq_m2b.txt).
+// Here `global_load_lds_dwordx4` writes 16 bytes per lane straight into LDS (a wave moves four
+// 256-byte (entry, k) rows per instruction), no staging registers exist, and the loads for chunk
+// c+2 are issued before the multiplies of chunk c: two chunks (96 KB) in flight per workgroup.
+//   workgroup = 512 threads = 8 waves (4 x 2), C tile 32 x 16, each wave an 8 x 8 register tile;
+//   stage = A[32 rows][4 k][64 slots] + B[16 cols][4 k][64 slots] = 48 KB, 3 stages = 144 KB;
+//   one s_barrier per chunk; s_waitcnt vmcnt(n) by hand (the loads of younger chunks stay in flight).
+// Measured (M2b, 64^3, L=8): 2.51 ms against 2.57 ms for the register-staged kernel and a ~1.3 ms
+// v_mad_u64_u32 floor (tools/mac_rate.hip: 5.0 cycles per MAC in this register pattern).  Phase
+// timers (s_memtime) put only ~26 % of a wave's time in the multiply phase: 40 % waits for the
+// chunk's rows and 20 % at the barrier for the other waves' rows - 48 KB per chunk per CU through
+// the vector-memory path is the limit (5 TB/s L2 -> CU in aggregate), not latency: issuing two
+// chunks ahead instead of one changes nothing.  The next step is traffic per MAC (a larger C tile
+// per CU), which needs the accumulators out of the VGPR file.
+// Requires inner % 4 == 0 (no way to zero-fill a partial chunk without registers); ragged row /
+// column tiles clamp their addresses and skip the store.
+#include "common.h"
+#include "modarith.h"
+
+#include <utility>
+
+namespace mmdma {
+constexpr int KC = 4, TROWS = 32, TCOLS = 16, STAGES = 3;
+constexpr uint32_t ROW_WORDS = 64;
+constexpr uint32_t A_ROWS = TROWS * KC, B_ROWS = TCOLS * KC, STAGE_ROWS = A_ROWS + B_ROWS;
+constexpr uint32_t STAGE_WORDS = STAGE_ROWS * ROW_WORDS;
+constexpr size_t LDS_BYTES = static_cast<size_t>(STAGES) * STAGE_WORDS * sizeof(uint32_t);
+constexpr int LOADS_PER_WAVE = STAGE_ROWS / 4 / 8;  // 6 instructions per wave per stage
+
+// s_waitcnt with only vmcnt constrained (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8])
+#define MMDMA_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | (0x7 << 4) | (0xF << 8))
+
+// LDS reads are issued by hand: the compiler hoists every ds_read of an unrolled chunk to its top
+// (and then runs out of registers), which puts all eight waves on the LDS port at once right after
+// the barrier.  Two dwords 256*OFF0 and 256*OFF1 bytes past `addr`:
+template <int OFF0, int OFF1>
+__device__ __forceinline__ uint64_t ds_read2st64(uint32_t addr) {
+    uint64_t v;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF0), "n"(OFF1));
+    return v;
+}
+// wait until at most N LDS reads issued after them are outstanding; ties the four words to the wait
+template <int N>
+__device__ __forceinline__ void lds_wait(uint64_t &x, uint64_t &y) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
+}
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int CNT, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, CNT>{}, static_cast<F &&>(f));
+}
+
+__global__ void __launch_bounds__(512, 2)
+    kernel_u32(uint32_t *__restrict__ C, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
+               const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L, uint32_t N,
+               uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks, uint32_t xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [STAGES][STAGE_ROWS][64]
+    const uint32_t tiles = row_tiles * col_tiles;
+    uint32_t id = blockIdx.x, tile, group;
+    if (xcd_remap) {
+        const uint32_t xcd = id & 7u, j = id >> 3;
+        tile = j % tiles;
+        group = (j / tiles) * 8u + xcd;
+    } else {
+        tile = id % tiles;
+        group = id / tiles;
+    }
+    const uint32_t limb = group / slot_chunks, chunk = group - limb * slot_chunks;
+    const uint32_t rt = tile / col_tiles, ct = tile - rt * col_tiles;
+    const uint32_t r0 = rt * TROWS, c0 = ct * TCOLS;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wr = wave >> 1, wc = wave & 1u;
+    const LimbConst lc = limbs[limb];
+    const uint32_t q = static_cast<uint32_t>(lc.q);
+    const size_t polyw = static_cast<size_t>(L) * N;
+    const size_t slot_base = static_cast<size_t>(limb) * N + chunk * 64u;
+
+    // loader: instruction j of this wave moves rows rho0 .. rho0+3 (rho0 = wave*24 + 4j); a lane
+    // supplies 16 bytes: row rho0 + lane/16, slots 4*(lane%16) .. +3
+    const uint32_t *src[LOADS_PER_WAVE];
+    const size_t stride_a = static_cast<size_t>(KC) * polyw, stride_b = static_cast<size_t>(KC) * cols * polyw;
+#pragma unroll
+    for (int j = 0; j < LOADS_PER_WAVE; ++j) {
+        const uint32_t rho = wave * (4 * LOADS_PER_WAVE) + 4 * j + (lane >> 4);
+        const uint32_t part = (lane & 15u) * 4u;
+        if (rho < A_ROWS) {
+            const uint32_t e = rho >> 2, k = rho & 3u;
+            const uint32_t rr = min(r0 + e, rows - 1);
+            src[j] = A + (static_cast<size_t>(rr) * inner + k) * polyw + slot_base + part;
+        } else {
+            const uint32_t rb = rho - A_ROWS, c = rb >> 2, k = rb & 3u;
+            const uint32_t cc = min(c0 + c, cols - 1);
+            src[j] = B + (static_cast<size_t>(k) * cols + cc) * polyw + slot_base + part;
+        }
+    }
+    auto issue = [&](uint32_t stage) {
+#pragma unroll
+        for (int j = 0; j < LOADS_PER_WAVE; ++j) {
+            const uint32_t rho0 = wave * (4 * LOADS_PER_WAVE) + 4 * j;  // wave-uniform
+            __builtin_amdgcn_global_load_lds(src[j], lds + stage * STAGE_WORDS + rho0 * ROW_WORDS, 16, 0, 0);
+            src[j] += rho0 < A_ROWS ? stride_a : stride_b;
+        }
+    };
+
+    uint64_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+
+    const uint32_t nch = inner / KC;
+    const uint32_t lazy = lc.lazy_terms;
+    uint32_t pending = 0;
+    // byte addresses inside LDS (the dynamic segment starts at LDS offset 0: no static __shared__ here)
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+    const uint32_t a_addr = lds0 + ((wr * 8u * KC) * ROW_WORDS + lane) * 4u;
+    const uint32_t b_addr = lds0 + ((A_ROWS + wc * 8u * KC) * ROW_WORDS + lane) * 4u;
+    constexpr uint32_t STAGE_BYTES = STAGE_WORDS * 4u;
+
+    // One iteration = one K-chunk.  a_cur holds this wave's A fragment (8 rows x 4 k, as pairs) of
+    // chunk ch; while column j is multiplied, column j+1's B values and row j of chunk ch+1's A
+    // fragment are read, so the LDS port works through the whole multiply phase instead of serving
+    // all eight waves back to back after the barrier with every SIMD idle.
+    auto step = [&](uint32_t ch, uint32_t stage, uint64_t (&a_cur)[8][2], uint64_t (&a_nxt)[8][2]) {
+        const uint32_t next_stage = stage + 1 == STAGES ? 0 : stage + 1;
+        const bool more = ch + 1 < nch;
+        if (more) MMDMA_WAIT_VM(0);               // chunk ch+1 (issued one iteration ago) has landed
+        asm volatile("s_barrier" ::: "memory");   // ... for every wave, and everyone is done with chunk ch-1
+        if (ch + 2 < nch) issue(next_stage + 1 == STAGES ? 0 : next_stage + 1);
+        const uint32_t sb = b_addr + stage * STAGE_BYTES;
+        const uint32_t sa = a_addr + (more ? next_stage : stage) * STAGE_BYTES;  // last chunk: harmless re-read
+        uint64_t b[2][2];
+        b[0][0] = ds_read2st64<0, 1>(sb);
+        b[0][1] = ds_read2st64<2, 3>(sb);
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int cur = j & 1, nxt = cur ^ 1;
+            if constexpr (j + 1 < 8) {
+                b[nxt][0] = ds_read2st64<4 * (j + 1), 4 * (j + 1) + 1>(sb);
+                b[nxt][1] = ds_read2st64<4 * (j + 1) + 2, 4 * (j + 1) + 3>(sb);
+            }
+            a_nxt[j][0] = ds_read2st64<4 * j, 4 * j + 1>(sa);
+            a_nxt[j][1] = ds_read2st64<4 * j + 2, 4 * j + 3>(sa);
+            // younger than b[cur]: the previous step's A row (2, none for j = 0) and this step's 2 or 4
+            lds_wait<(j == 0 ? 0 : 2) + (j + 1 < 8 ? 4 : 2)>(b[cur][0], b[cur][1]);
+            const uint32_t bk[KC] = {static_cast<uint32_t>(b[cur][0]), static_cast<uint32_t>(b[cur][0] >> 32),
+                                     static_cast<uint32_t>(b[cur][1]), static_cast<uint32_t>(b[cur][1] >> 32)};
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t av = (k & 1) ? static_cast<uint32_t>(a_cur[i][k >> 1] >> 32) : static_cast<uint32_t>(a_cur[i][k >> 1]);
+                    acc[i][j] += static_cast<uint64_t>(av) * bk[k];
+                }
+        });
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_wait<0>(a_nxt[i][0], a_nxt[i][1]);  // long since complete
+        pending += KC;
+        if (pending + KC > lazy) {
+            pending = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+        }
+    };
+
+    uint64_t a0[8][2], a1[8][2];
+    issue(0);
+    if (nch > 1) {
+        issue(1);
+        MMDMA_WAIT_VM(LOADS_PER_WAVE);
+    } else {
+        MMDMA_WAIT_VM(0);
+    }
+    asm volatile("s_barrier" ::: "memory");
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        a0[i][0] = ds_read2st64<4 * i, 4 * i + 1>(a_addr);
+        a0[i][1] = ds_read2st64<4 * i + 2, 4 * i + 3>(a_addr);
+    });
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lds_wait<0>(a0[i][0], a0[i][1]);
+    uint32_t stage = 0;
+    for (uint32_t ch = 0; ch < nch; ch += 2) {
+        step(ch, stage, a0, a1);
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+        if (ch + 1 < nch) {
+            step(ch + 1, stage, a1, a0);
+            stage = stage + 1 == STAGES ? 0 : stage + 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = r0 + wr * 8 + i;
+        if (r >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t c = c0 + wc * 8 + j;
+            if (c >= cols) continue;
+            C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+        }
+    }
+}
+}  // namespace mmdma
+
+// -1: shape not supported (the caller falls back to the register-staged LDS kernel)
+int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    GpuContext *ctx = out->ctx;
+    const uint32_t rows = static_cast<uint32_t>(lhs->rows), inner = static_cast<uint32_t>(lhs->cols),
+                   cols = static_cast<uint32_t>(rhs->cols);
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(out)), N = static_cast<uint32_t>(ctx->N);
+    if (ctx->wide || N < 64 || (N % 64) != 0 || inner < mmdma::KC || (inner % mmdma::KC) != 0) return -1;
+    const uint32_t row_tiles = (rows + mmdma::TROWS - 1) / mmdma::TROWS, col_tiles = (cols + mmdma::TCOLS - 1) / mmdma::TCOLS;
+    const uint32_t slot_chunks = N / 64;
+    const uint64_t groups = static_cast<uint64_t>(L) * slot_chunks;
+    const uint64_t blocks = groups * row_tiles * col_tiles;
+    if (blocks > 0x7fffffffull) return set_error("gpu_matrix_mul: matrix too large");
+    static std::atomic<uint64_t> configured{0};
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (!(configured.load() & bit)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mmdma::kernel_u32),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mmdma::LDS_BYTES)));
+        configured.fetch_or(bit);
+    }
+    const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
+    hipLaunchKernelGGL(mmdma::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(512), mmdma::LDS_BYTES, ctx->stream,
+                       static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
+                       static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
+                       col_tiles, slot_chunks, remap);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

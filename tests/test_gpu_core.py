@@ -181,6 +181,24 @@ def test_matmul_kernel_families(gpu, oracle, path, shape):
         del os.environ["MXX_HIP_MATMUL_PATH"]
 
 
+@pytest.mark.parametrize("shape", [(32, 8, 16), (33, 12, 17), (64, 64, 64), (16, 4, 8), (40, 36, 5), (3, 16, 70)])
+@pytest.mark.parametrize("bits", [24, 31])
+def test_matmul_dma_kernel(gpu, oracle, monkeypatch, shape, bits):
+    """global->LDS streamed product (matmul_dma.hip): full and ragged 32x16 tiles, inner % 4 == 0, and
+    31-bit primes whose accumulators must be folded every chunk; worst-case residues q-1 in one operand."""
+    r, k, c = shape
+    n = 128
+    moduli = oracle.gen_crt_basis(n, 2, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 8)
+    a = rand_matrix(oracle, 27, r, k, moduli, n)
+    b = np.broadcast_to((np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1), (k, c, len(moduli), n)).copy()
+    b[::2] = rand_matrix(oracle, 28, k, c, moduli, n)[::2]
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    monkeypatch.setenv("MXX_HIP_MATMUL_PATH", "dma")
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+
+
 def test_matmul_lds_lazy_window_31bit(gpu, oracle):
     """LDS kernel with 31-bit primes: the 64-bit accumulators must be folded every chunk."""
     n = 64
