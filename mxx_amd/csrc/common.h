@@ -95,6 +95,22 @@ struct GpuP1CovarianceCache {
     void *karney_div = nullptr;      // [coeff][row] KarneyDivisor of sqrt_var (rng.h)
 };
 
+// ---- one thread per item -----------------------------------------------------------------------
+// HIP rejects launches with gridDim.x * blockDim.x >= 2^32 ("invalid configuration argument"), which a
+// 64x1024 gadget matrix at n = 2^14 already exceeds: such kernels use item_grid() / item_index().
+static inline dim3 item_grid(size_t items, unsigned threads) {
+    const size_t blocks = (items + threads - 1) / threads;
+    const size_t max_x = (static_cast<size_t>(1) << 31) / threads;
+    if (blocks <= max_x) return dim3(static_cast<unsigned>(blocks ? blocks : 1));
+    const size_t y = (blocks + max_x - 1) / max_x;
+    return dim3(static_cast<unsigned>((blocks + y - 1) / y), static_cast<unsigned>(y));
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ size_t item_index() {
+    return (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+}
+#endif
+
 // ---- error plumbing ---------------------------------------------------------
 int set_error(const char *msg);
 int set_error(const std::string &msg);

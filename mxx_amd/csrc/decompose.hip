@@ -24,7 +24,7 @@ __global__ void decompose_kernel(W *__restrict__ out, const W *__restrict__ src,
                                  size_t src_polys, uint32_t src_cols, uint32_t L, uint32_t N, uint32_t towers,
                                  uint32_t dpt, uint32_t base_bits, size_t k) {
     // item = (src poly, tower, coefficient)
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     const size_t total = src_polys * towers * N;
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx % N);
@@ -56,7 +56,7 @@ __global__ void decompose_kernel(W *__restrict__ out, const W *__restrict__ src,
 template <typename W>
 __global__ void fill_gadget_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t rows, size_t cols,
                                    uint32_t L, uint32_t N, uint32_t dpt, size_t k, uint32_t base_bits, int small) {
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     const size_t total = rows * cols * L * N;
     if (idx >= total) return;
     const size_t pl = idx / N;
@@ -109,13 +109,13 @@ static int fill_gadget_impl(GpuMatrix *out, uint32_t base_bits, bool small) {
     const size_t total = matrix_words(out);
     if (total == 0) return 0;
     if (ctx_activate(ctx)) return 1;
-    const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+    const dim3 blocks = item_grid(total, 256);
     if (ctx->wide)
-        hipLaunchKernelGGL(fill_gadget_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(fill_gadget_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(out->data), ctx->d_limbs, out->rows, out->cols, (uint32_t)L,
                            (uint32_t)ctx->N, dpt, k, base_bits, small ? 1 : 0);
     else
-        hipLaunchKernelGGL(fill_gadget_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(fill_gadget_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(out->data), ctx->d_limbs, out->rows, out->cols, (uint32_t)L,
                            (uint32_t)ctx->N, dpt, k, base_bits, small ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -167,13 +167,13 @@ static int decompose_impl(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *o
         }
     }
     const size_t total = polys * towers * static_cast<size_t>(ctx->N);
-    const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+    const dim3 blocks = item_grid(total, 256);
     if (ctx->wide)
-        hipLaunchKernelGGL(decompose_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(decompose_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(out->data), static_cast<const uint64_t *>(coeff), ctx->d_limbs, polys,
                            (uint32_t)src->cols, (uint32_t)L, (uint32_t)ctx->N, towers, dpt, base_bits, k);
     else
-        hipLaunchKernelGGL(decompose_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(decompose_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(coeff), ctx->d_limbs, polys,
                            (uint32_t)src->cols, (uint32_t)L, (uint32_t)ctx->N, towers, dpt, base_bits, k);
     HIP_TRY(hipGetLastError());

@@ -43,7 +43,7 @@ __global__ void pack_rns_kernel(const W *__restrict__ src, uint64_t *__restrict_
 template <typename W>
 __global__ void const_coeff_kernel(const W *__restrict__ src, uint64_t *__restrict__ dst, size_t polys, size_t limbs,
                                    size_t N, size_t words_per_poly_dst) {
-    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t idx = item_index();
     if (idx >= polys * limbs) return;
     size_t poly = idx / limbs, l = idx - poly * limbs;
     dst[poly * words_per_poly_dst + l] = static_cast<uint64_t>(src[(poly * limbs + l) * N]);
@@ -73,7 +73,7 @@ __global__ void block_rect_kernel(W *__restrict__ dst, const W *__restrict__ src
 template <typename W>
 __global__ void scatter_i64_kernel(W *__restrict__ dst, const int64_t *__restrict__ vals,
                                    const LimbConst *__restrict__ limbs, size_t polys, uint32_t L, uint32_t N) {
-    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t idx = item_index();
     size_t total = polys * N;
     if (idx >= total) return;
     size_t poly = idx / N;
@@ -103,7 +103,7 @@ int launch_scatter_i64(GpuMatrix *out, const int64_t *vals) {
     size_t polys = matrix_polys(out);
     if (polys == 0) return 0;
     size_t total = polys * ctx->N;
-    unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+    const dim3 blocks = item_grid(total, 256);
     uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
     if (ctx->wide)
         hipLaunchKernelGGL(scatter_i64_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
@@ -386,7 +386,7 @@ extern "C" int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t
     size_t bytes = polys * words_per_poly * 8;
     if (ctx_alloc(ctx, bytes, &stage)) return 1;
     if (words_per_poly != L) HIP_TRY(hipMemsetAsync(stage, 0, bytes, ctx->stream));
-    unsigned blocks = static_cast<unsigned>((polys * L + 255) / 256);
+    const dim3 blocks = item_grid(polys * L, 256);
     if (ctx->wide)
         hipLaunchKernelGGL(const_coeff_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<const uint64_t *>(mat->data), static_cast<uint64_t *>(stage), polys, L,

@@ -76,7 +76,7 @@ __global__ void ntt_stage_global_kernel(W *__restrict__ data, const W *__restric
                                         const W *__restrict__ tws_all, const LimbConst *__restrict__ limbs, uint32_t L,
                                         uint32_t logN, uint32_t m, uint32_t logt, size_t vectors) {
     const size_t half = static_cast<size_t>(1) << (logN - 1);
-    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t idx = item_index();
     if (idx >= vectors * half) return;
     const size_t vec = idx >> (logN - 1);
     const uint32_t b = static_cast<uint32_t>(idx & (half - 1));
@@ -104,7 +104,7 @@ __global__ void ntt_stage_global_kernel(W *__restrict__ data, const W *__restric
 template <typename W>
 __global__ void ntt_scale_global_kernel(W *__restrict__ data, const LimbConst *__restrict__ limbs, uint32_t L,
                                         uint32_t logN, size_t total) {
-    size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t idx = item_index();
     if (idx >= total) return;
     const uint32_t limb = static_cast<uint32_t>((idx >> logN) % L);
     const W q = static_cast<W>(limbs[limb].q);
@@ -139,23 +139,23 @@ static int launch_global(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
     const uint32_t logN = ctx->logN;
     const size_t half = size_t(1) << (logN - 1);
     const size_t total = vectors * half;
-    const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+    const dim3 blocks = item_grid(total, 256);
     const W *tw = static_cast<const W *>(INV ? ctx->d_tw_inv : ctx->d_tw_fwd);
     const W *tws = static_cast<const W *>(INV ? ctx->d_tw_inv_sh : ctx->d_tw_fwd_sh);
     if (!INV) {
         uint32_t logt = logN - 1;
         for (uint32_t m = 1; m < (1u << logN); m <<= 1, --logt) {
-            hipLaunchKernelGGL((ntt_stage_global_kernel<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, data, tw,
+            hipLaunchKernelGGL((ntt_stage_global_kernel<W, false>), blocks, dim3(256), 0, ctx->stream, data, tw,
                                tws, ctx->d_limbs, L, logN, m, logt, vectors);
         }
     } else {
         uint32_t logt = 0;
         for (uint32_t m = 1u << (logN - 1); m >= 1; m >>= 1, ++logt) {
-            hipLaunchKernelGGL((ntt_stage_global_kernel<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, data, tw,
+            hipLaunchKernelGGL((ntt_stage_global_kernel<W, true>), blocks, dim3(256), 0, ctx->stream, data, tw,
                                tws, ctx->d_limbs, L, logN, m, logt, vectors);
         }
         const size_t words = vectors << logN;
-        hipLaunchKernelGGL(ntt_scale_global_kernel<W>, dim3(static_cast<unsigned>((words + 255) / 256)), dim3(256), 0,
+        hipLaunchKernelGGL(ntt_scale_global_kernel<W>, item_grid(words, 256), dim3(256), 0,
                            ctx->stream, data, ctx->d_limbs, L, logN, words);
     }
     HIP_TRY(hipGetLastError());

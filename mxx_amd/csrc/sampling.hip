@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict_
         keys[threadIdx.x] = uniform ? chacha_subkey(seed, static_cast<uint64_t>(threadIdx.x) + 1, kTagUniform)
                                     : chacha_subkey(seed, 0, dist == GPU_MATRIX_DIST_BIT ? kTagBit : kTagTernary);
     __syncthreads();
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     if (idx >= polys * N) return;
     const size_t p = idx / N;
     const uint32_t i = static_cast<uint32_t>(idx - p * N);
@@ -142,7 +142,7 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
         HIP_TRY(err);
         if (rc) return rc;
     } else {
-        const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+        const dim3 blocks = item_grid(total, 256);
         if (ctx->wide)
             hipLaunchKernelGGL(sample_distribution_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                                static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,

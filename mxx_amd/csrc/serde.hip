@@ -86,7 +86,7 @@ template <typename W>
 __global__ void compact_maxbits_kernel(const W *__restrict__ src, size_t polys, uint32_t N, SerdeConsts sc,
                                        const uint64_t *__restrict__ garner, size_t garner_stride,
                                        unsigned int *__restrict__ max_bits) {
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     unsigned int bits = 0;
     if (idx < polys * N) {
         uint64_t x[kMaxWords];
@@ -102,7 +102,7 @@ template <typename W>
 __global__ void compact_pack_kernel(const W *__restrict__ src, size_t polys, uint32_t N, SerdeConsts sc,
                                     const uint64_t *__restrict__ garner, size_t garner_stride, uint32_t width,
                                     uint32_t *__restrict__ payload_words) {
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     if (idx >= polys * N) return;
     uint64_t x[kMaxWords + 1];
     bool neg;
@@ -130,7 +130,7 @@ __global__ void compact_pack_kernel(const W *__restrict__ src, size_t polys, uin
 template <typename W>
 __global__ void compact_unpack_kernel(W *__restrict__ dst, const uint8_t *__restrict__ payload, size_t polys,
                                       uint32_t N, SerdeConsts sc, uint32_t width) {
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     if (idx >= polys * N) return;
     const size_t poly = idx / N;
     const uint32_t i = static_cast<uint32_t>(idx % N);
@@ -216,17 +216,17 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     if (build_consts(mat, sc)) return 1;
     const uint32_t N = static_cast<uint32_t>(ctx->N);
     const size_t coeffs = polys * N;
-    const unsigned blocks = static_cast<unsigned>((coeffs + 255) / 256);
+    const dim3 blocks = item_grid(coeffs, 256);
     const size_t gstride = static_cast<size_t>(ctx->limb_count);
     void *d_max = nullptr;
     if (ctx_alloc(ctx, sizeof(unsigned int), &d_max)) return 1;
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned int), ctx->stream));
     if (ctx->wide)
-        hipLaunchKernelGGL(compact_maxbits_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(compact_maxbits_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride,
                            static_cast<unsigned int *>(d_max));
     else
-        hipLaunchKernelGGL(compact_maxbits_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(compact_maxbits_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride,
                            static_cast<unsigned int *>(d_max));
     HIP_TRY(hipGetLastError());
@@ -247,11 +247,11 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
         if (ctx_alloc(ctx, padded, &d_payload)) return 1;
         HIP_TRY(hipMemsetAsync(d_payload, 0, padded, ctx->stream));
         if (ctx->wide)
-            hipLaunchKernelGGL(compact_pack_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(compact_pack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                                static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride, width,
                                static_cast<uint32_t *>(d_payload));
         else
-            hipLaunchKernelGGL(compact_pack_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(compact_pack_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                                static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride, width,
                                static_cast<uint32_t *>(d_payload));
         HIP_TRY(hipGetLastError());
@@ -291,13 +291,13 @@ extern "C" int gpu_matrix_load_compact_bytes(GpuMatrix *mat, const uint8_t *payl
         if (ctx_alloc(ctx, payload_len, &d_payload)) return 1;
         HIP_TRY(hipMemcpyAsync(d_payload, payload, payload_len, hipMemcpyHostToDevice, ctx->stream));
     }
-    const unsigned blocks = static_cast<unsigned>((coeffs + 255) / 256);
+    const dim3 blocks = item_grid(coeffs, 256);
     if (ctx->wide)
-        hipLaunchKernelGGL(compact_unpack_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(compact_unpack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(mat->data), static_cast<const uint8_t *>(d_payload), polys, N, sc,
                            static_cast<uint32_t>(max_coeff_bits));
     else
-        hipLaunchKernelGGL(compact_unpack_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(compact_unpack_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(mat->data), static_cast<const uint8_t *>(d_payload), polys, N, sc,
                            static_cast<uint32_t>(max_coeff_bits));
     HIP_TRY(hipGetLastError());

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out,
                                      uint32_t L, uint32_t N, uint32_t dpt, uint32_t base_bits, double c, size_t k,
                                      GpuRngSeed seed) {
     __shared__ uint64_t ring[128 * RNG_RING_WORDS];
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     const size_t total = src_polys * L * N;
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx % N);
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
                                        const ChaChaKey *__restrict__ keys, size_t total, uint32_t L, uint32_t logN,
                                        uint32_t dpt, uint32_t base_bits, double c) {
     __shared__ uint64_t ring[256 * RNG_RING_WORDS];
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
     const uint32_t pt = static_cast<uint32_t>(idx >> logN);
@@ -363,7 +363,7 @@ template <typename W>
 __global__ void __launch_bounds__(256) gauss_samp_expand_kernel(W *__restrict__ out, const int64_t *__restrict__ stage,
                                          const LimbConst *__restrict__ limbs, size_t total, uint32_t src_cols, uint32_t L,
                                          uint32_t logN, uint32_t dpt, uint32_t k) {
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
     const uint32_t pt = static_cast<uint32_t>(idx >> logN);
@@ -399,7 +399,7 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
                        static_cast<ChaChaKey *>(keys), N, seed);
     hipLaunchKernelGGL(gq_tower_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<GqTower *>(towers), ctx->d_limbs,
                        L, dpt, base_bits, c);
-    hipLaunchKernelGGL((gauss_samp_prep_kernel<W, MAXD>), dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
                        ctx->stream, a_words, left_words, src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys), total, L,
                        ctx->logN, dpt, base_bits, c);
     const uint32_t per_lane =
@@ -410,7 +410,7 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
                        static_cast<int64_t *>(stage), src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys),
                        static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
                        base_bits, c, karney_divisor(sigma), per_lane);
-    hipLaunchKernelGGL(gauss_samp_expand_kernel<W>, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
                        ctx->stream, out, static_cast<const int64_t *>(stage), ctx->d_limbs, total, src_cols, L, ctx->logN,
                        dpt, static_cast<uint32_t>(k));
     const hipError_t err = hipGetLastError();
@@ -431,7 +431,7 @@ static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys
     const bool simple = mode && mode[0] == 's';
     if (!simple && dpt <= 2) return launch_gauss_samp_lanes<W, 2>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
     if (!simple && dpt <= 4) return launch_gauss_samp_lanes<W, 4>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
-    const unsigned blocks = static_cast<unsigned>((total + 127) / 128);
+    const dim3 blocks = item_grid(total, 128);
     const uint32_t N = static_cast<uint32_t>(ctx->N);
 #define LAUNCH_GS(MAXD)                                                                                        \
     hipLaunchKernelGGL((gauss_samp_gq_kernel<W, MAXD>), dim3(blocks), dim3(128), 0, ctx->stream, out, src,      \
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
                                  uint32_t N, uint64_t q0, double c_scale, GpuRngSeed seed,
                                  double *__restrict__ mean_ws) {
     __shared__ uint64_t ring[128 * RNG_RING_WORDS];
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     if (idx >= static_cast<size_t>(cols) * N) return;
     const uint32_t col = static_cast<uint32_t>(idx / N);
     const uint32_t i = static_cast<uint32_t>(idx - static_cast<size_t>(col) * N);
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
 }
 
 __global__ void p1_divisor_kernel(KarneyDivisor *__restrict__ div, const double *__restrict__ sqrt_var, size_t count) {
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t idx = item_index();
     if (idx < count) div[idx] = karney_divisor(sqrt_var[idx]);
 }
 
@@ -821,7 +821,7 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
         out->format = GPU_POLY_FORMAT_EVAL;
         return 0;
     }
-    const unsigned blocks = static_cast<unsigned>((total + 127) / 128);
+    const dim3 blocks = item_grid(total, 128);
     void *mean_ws = nullptr;
     if (m > 8 && ctx_alloc(ctx, total * m * sizeof(double), &mean_ws)) return 1;
 #define LAUNCH_P1(WT, MAXM)                                                                                       \

@@ -1,0 +1,77 @@
+"""GPU: size-independent properties at BASELINE.json's full shapes (the oracle cannot finish these
+sizes in seconds, so parity is carried by exact algebraic identities on device-sampled inputs).
+
+  M2a  bench_matrix_mul shape  (n=2^14, L=15, 1x30 * 30x120): distributivity and scalar associativity
+  M2b  config 3                (n=2^14, L=8, 64x64): G * G^-1(M) == M through the fused decompose and the
+                               streamed product with inner dimension 1024; (A*B)*C == A*(B*C)
+  M3a  bench_preimage shape    (n=2^14, L=10, 50 columns): A*x == u and the limb-0 infinity norm of x
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import make_params
+
+pytestmark = pytest.mark.gpu
+
+N = 16384
+
+
+def test_m2a_distributive_and_scalar_associative(gpu, oracle):
+    p = make_params(gpu, oracle, N, 15, 24, 12)
+    us = gpu.GpuDCRTPolyUniformSampler()
+    u = gpu.DistType.FinRingDist()
+    a = us.sample_uniform(p, 1, 30, u)
+    b1 = us.sample_uniform(p, 30, 120, u)
+    b2 = us.sample_uniform(p, 30, 120, u)
+    assert a * (b1 + b2) == a * b1 + a * b2
+    s = us.sample_poly(p, u)
+    assert (a * b1) * s == a * (b1 * s)
+    assert not (a * b1 == a * b2)
+
+
+def test_m2b_gadget_inverse_and_associativity(gpu, oracle):
+    p = make_params(gpu, oracle, N, 8, 24, 12)
+    us = gpu.GpuDCRTPolyUniformSampler()
+    u = gpu.DistType.FinRingDist()
+    m = us.sample_uniform(p, 64, 64, u)
+    dec = m.decompose()                       # 1024 x 64, fused digit + NTT kernel
+    k = p.modulus_digits()
+    assert dec.size() == (64 * k, 64) and dec.is_ntt
+    g = gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 64)
+    assert g * dec == m                       # inner dimension 1024
+    del dec, g
+    a = us.sample_uniform(p, 64, 64, u)
+    b = us.sample_uniform(p, 64, 64, u)
+    assert (a * b) * m == a * (b * m)
+    # digits are small: every coefficient of G^-1(M) is below the base in every limb
+    d_small = us.sample_uniform(p, 2, 2, u).decompose().to_coeff_rns()
+    assert int(d_small.max()) < (1 << 12)
+
+
+def test_m3a_preimage_relation_and_norm(gpu, oracle):
+    p = make_params(gpu, oracle, N, 10, 24, 12)
+    sigma, base = 4.578, 12
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, sigma)
+    td, A = sampler.trapdoor(p, 1)
+    k = p.modulus_digits()
+    target = gpu.GpuDCRTPolyUniformSampler().sample_uniform(p, 1, 50, gpu.DistType.FinRingDist())
+    x = sampler.preimage(p, td, A, target)
+    assert x.size() == (k + 2, 50)
+    assert A * x == target
+    # x is one integer vector, |x| < 6.5 s ~ 2^30 > q_i/2: rebuild it from limbs 0 and 1 (Garner), centre it
+    # modulo q0*q1, and check that limb 2 holds the same integer
+    xr = x.to_coeff_rns()
+    q0, q1, q2 = (int(q) for q in p.moduli()[:3])
+    r0, r1, r2 = (xr[:, :, l].astype(np.int64) for l in range(3))
+    t = ((r1 - r0) % q1 * pow(q0, -1, q1)) % q1
+    v = r0 + q0 * t
+    v = np.where(v > (q0 * q1) // 2, v - q0 * q1, v)
+    assert np.array_equal(v % q2, r2)
+    c = ((1 << base) + 1) * sigma
+    s_par = 1.8 * ((1 << base) + 1) * sigma * sigma * (math.sqrt(N * k) + math.sqrt(2 * N) + 4.7)
+    # rows 0..1 carry p1 + [R;E] z, the rest p2 + z with p2 of width sqrt(s^2 - c^2)
+    assert np.abs(v).max() < 6.5 * s_par
+    width = math.sqrt(s_par * s_par - c * c)
+    assert 0.9 * width < v[2:].std() < 1.1 * width
