@@ -134,11 +134,6 @@ __device__ __forceinline__ void lds_set_addr(uint32_t tid, int g, uint32_t &bi, 
     pbase = lds_pad_c(bi * B + r);
 }
 
-template <int S, int u>
-struct LdsOff {
-    static constexpr uint32_t value = lds_pad_c(static_cast<uint32_t>(S) * u);
-};
-
 template <typename W, int LOGN, int LOGR, int WAVES_PER_EU>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
