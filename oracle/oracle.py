@@ -11,6 +11,7 @@ shape (rows, cols, L, n).
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -386,3 +387,58 @@ def compact_payload(coeff_rns: np.ndarray, moduli):
         stream |= (m | (s << (width - 1))) << (idx * width) if width else 0
     nbytes = (len(vals) * width + 7) // 8
     return stream.to_bytes(nbytes, "little"), width, (width + 7) // 8
+
+
+# ---- trapdoor generation and preimage, end to end on the CPU -------------------------------------
+# Restates the reference's GPU preimage sequence (src/sampler/trapdoor/gpu.rs:69-80,202-215,228-369,
+# 423-474; constants :15-27) with the functions above.  Matrices are EVAL residues (rows, cols, L, n).
+def _seed_from(seed, salt: int):
+    w = _seed_words(seed).copy()
+    w[0] ^= np.uint64(0x9e3779b97f4a7c15 * (salt + 1) & 0xFFFFFFFFFFFFFFFF)
+    return w
+
+
+def preimage_params(moduli, n: int, base_bits: int, sigma: float, d: int):
+    k = digits_per_tower(moduli, base_bits) * len(moduli)
+    b = float(1 << base_bits)
+    c = (b + 1.0) * sigma
+    s = 1.8 * (b + 1.0) * sigma * sigma * (math.sqrt(d * n * k) + math.sqrt(2 * n) + 4.7)
+    return k, c, s
+
+
+def trapdoor_gen(moduli, n: int, base_bits: int, sigma: float, d: int, seed):
+    """R, E ~ D_sigma^{d x dk}; A = [Abar | I_d | G - (Abar R + E)] (gpu.rs:202-215)."""
+    k, _, _ = preimage_params(moduli, n, base_bits, sigma, d)
+    L = len(moduli)
+    r = matrix_ntt(sample_distribution(d, d * k, moduli, n, "gauss", sigma, _seed_from(seed, 0)), moduli)
+    e = matrix_ntt(sample_distribution(d, d * k, moduli, n, "gauss", sigma, _seed_from(seed, 1)), moduli)
+    abar = matrix_ntt(sample_distribution(d, d, moduli, n, "uniform", 0.0, _seed_from(seed, 2)), moduli)
+    ident = np.zeros((d, d, L, n), dtype=np.uint64)
+    for i in range(d):
+        ident[i, i] = 1  # EVAL form of the constant 1
+    g = gadget_matrix(d, moduli, n, base_bits)
+    a1 = pointwise("sub", g, pointwise("add", matmul(abar, r, moduli, fast=True), e, moduli), moduli)
+    return r, e, np.concatenate([abar, ident, a1], axis=1)
+
+
+def preimage(moduli, n: int, base_bits: int, sigma: float, r, e, a, target, seed, cov=None):
+    """x with a * x == target (gpu.rs:228-369).  `cov` = p1_covariance(...) of this trapdoor, if cached."""
+    d, dk = r.shape[0], r.shape[1]
+    cols = target.shape[1]
+    k, c, s = preimage_params(moduli, n, base_bits, sigma, d)
+    assert dk == d * k and a.shape[1] == dk + 2 * d
+    re = np.concatenate([r, e], axis=0)
+    if cov is None:
+        rt, et = np.swapaxes(r, 0, 1), np.swapaxes(e, 0, 1)
+        inv = lambda m: matrix_ntt(m, moduli, inverse=True)
+        cov = p1_covariance(inv(matmul(r, rt, moduli, fast=True)), inv(matmul(r, et, moduli, fast=True)),
+                            inv(matmul(e, et, moduli, fast=True)), moduli, c, s, sigma)
+    sv, up = cov
+    p2 = matrix_ntt(sample_distribution(dk, cols, moduli, n, "gauss", math.sqrt(s * s - c * c), _seed_from(seed, 3)), moduli)
+    tp2 = matrix_ntt(matmul(re, p2, moduli, fast=True), moduli, inverse=True)
+    p1 = matrix_ntt(sample_p1(tp2, moduli, sv, up, -(c * c) / (s * s - c * c), _seed_from(seed, 4)), moduli)
+    p_hat = pointwise("add", matmul(a[:, : 2 * d], p1, moduli, fast=True), matmul(a[:, 2 * d :], p2, moduli, fast=True), moduli)
+    pert = matrix_ntt(pointwise("sub", target, p_hat, moduli), moduli, inverse=True)
+    z = matrix_ntt(gauss_samp_gq(pert, moduli, base_bits, c, _seed_from(seed, 5)), moduli)
+    top = pointwise("add", p1, matmul(re, z, moduli, fast=True), moduli)
+    return np.concatenate([top, pointwise("add", p2, z, moduli)], axis=0)
