@@ -54,6 +54,8 @@ struct GpuContext {
     void *d_tw2_fwd = nullptr;     // [limb][N] pairs {-w mod 2^W, Shoup(w)} for the lazy forward kernel
     void *d_tw2_inv = nullptr;     // [limb][N] pairs {w, Shoup(w)} for the lazy inverse kernel
     bool lazy_ok = false;          // every modulus < 2^(W-7): lazy LDS kernels are valid
+    void *d_tw2s_inv = nullptr;    // u32 words, moduli < 2^24: inverse pairs {centred w, floor(w 2^32 / q)} as int32 (ntt14.h)
+    bool signed_ok = false;
     uint64_t *d_garner = nullptr;  // [limb][limb] : inverse of q_j mod q_i for j<i
     std::vector<uint64_t> garner_inv;  // host copy
     std::vector<LimbConst> limbs;      // host copy

@@ -162,8 +162,9 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_body<W>(out + vec * N, load, tw_all, lc, limb);
 }
 
-template <typename W>
-__global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
+// SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)
+template <typename W, bool SGN>
+__global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
     inv_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                uint32_t L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,8 +192,13 @@ __global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
             const W *src = g + B * BLK + 8 * lane;
 #pragma unroll
             for (int m = 0; m < 8; m += VN) *reinterpret_cast<V16 *>(&v[m]) = *reinterpret_cast<const V16 *>(src + m);
-            gs_network_lazy<W, 3, false>(v, tw, B * 64u + lane, 11, q, lc);
-            gs_fold<W, 3>(v, q, muw);
+            if constexpr (SGN) {  // canonical inputs (exponent 0); keep exponents <= 2
+                gs_network_signed<3, false>(v, tw, B * 64u + lane, 11, q, lc);
+                gs_fold_signed<3, 0, 2>(v, q, muw);
+            } else {
+                gs_network_lazy<W, 3, false>(v, tw, B * 64u + lane, 11, q, lc);
+                gs_fold<W, 3>(v, q, muw);
+            }
             const uint32_t base = pad64(8 * lane);
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + m] = v[m];
@@ -203,8 +209,13 @@ __global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
             const uint32_t base = 72 * c + j;
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m];
-            gs_network_lazy<W, 3, false>(v, tw, B * 8u + c, 8, q, lc);
-            gs_fold<W, 3>(v, q, muw);
+            if constexpr (SGN) {  // inputs <= 2 (which of them depends on the lane): keep <= 3
+                gs_network_signed<3, false>(v, tw, B * 8u + c, 8, q, lc);
+                gs_fold_signed<3, 2, 3>(v, q, muw);
+            } else {
+                gs_network_lazy<W, 3, false>(v, tw, B * 8u + c, 8, q, lc);
+                gs_fold<W, 3>(v, q, muw);
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + 8 * m] = v[m];
         }
@@ -212,8 +223,13 @@ __global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
         {   // stages 7,6,5 (wave-uniform twiddles)
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[lane + 72 * m];
-            gs_network_lazy<W, 3, false>(v, tw, B, 5, q, lc);
-            gs_fold<W, 3>(v, q, muw);
+            if constexpr (SGN) {  // inputs <= 3 (butterfly inputs reach 5); the register pass wants 1
+                gs_network_signed<3, false>(v, tw, B, 5, q, lc);
+                gs_fold_signed<3, 3, 1>(v, q, muw);
+            } else {
+                gs_network_lazy<W, 3, false>(v, tw, B, 5, q, lc);
+                gs_fold<W, 3>(v, q, muw);
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[lane + 72 * m] = v[m];
         }
@@ -223,7 +239,8 @@ __global__ void __launch_bounds__(512, 6 / (sizeof(W) / 4))
         for (int m = 0; m < 8; ++m) h[8 * grp + m] = x[m * BLK_PAD + pad64(tid)];
     }
     // stages 4..0 in registers (N^-1 folded into the last one), coalesced per u
-    gs_network_lazy<W, 5, true>(h, tw, 0, 0, q, lc);
+    if constexpr (SGN) gs_network_signed<5, true>(h, tw, 0, 0, q, lc);
+    else gs_network_lazy<W, 5, true>(h, tw, 0, 0, q, lc);
 #pragma unroll
     for (int u = 0; u < R0; ++u) g[tid + T * u] = csub<W>(h[u], q);
 }

@@ -113,6 +113,63 @@ __device__ __forceinline__ void gs_fold(W (&v)[1 << C], W q, W muw) {
     }
 }
 
+// ---- signed lazy butterflies for the inverse transform (u32 words, q < 2^24; used by ntt14.h) -----
+// Values are int32 in redundant form.  With the centred twiddle w^ in (-q/2, q/2] and
+// w^' = floor(w^ 2^32 / q), T = D w^ - mulhi_i32(D, w^') q equals D w (mod q) and lies in
+// (-q |D| / 2^32, q + q |D| / 2^32): (-q/4, 5q/4) for |D| < 2^30.  The Gentleman-Sande butterfly becomes
+// A = X + Y, D = X - Y (no +M offset to keep the difference non-negative: one VALU op less per butterfly)
+// and B = T.  The A path doubles per stage; folds (x - mulhi_i32(x, floor(2^32/q)) q, same output range)
+// keep every butterfly input below 2^5 q, so |X - Y| < 2^30.  Measured on the 2^14 inverse: 1970 -> 1726
+// VALU instructions per thread, 156 -> ~138 us for M1.  The same idea in the forward transform
+// (A = U + T, B = U - T instead of the 3-operand B = U + 2q + nT) is slower in the kernel (148 vs 137 us)
+// although it wins in isolation (tools/bfly_forms.hip): the compiler splits the v_mad_u64_u32 into
+// v_mul_lo + v_sub once the product is subtracted, and instruction count matters more than operand count.
+__device__ __forceinline__ uint32_t smul_lazy(uint32_t x, uint32_t w, uint32_t ws, uint32_t q) {
+    return x * w - static_cast<uint32_t>(__mulhi(static_cast<int32_t>(x), static_cast<int32_t>(ws))) * q;
+}
+// bound exponent (|x| < 2^e q) of element u after the stages that used bits 0..j, all inputs at e0
+__host__ __device__ constexpr int gs_exp_from(int e0, int u, int j) {
+    int e = e0;
+    for (int i = 0; i <= j; ++i) e = ((u >> i) & 1) ? 1 : e + 1;
+    return e;
+}
+
+template <int C, bool LAST>
+__device__ __forceinline__ void gs_network_signed(uint32_t (&v)[1 << C], const TwPair<uint32_t> *__restrict__ tw,
+                                                  uint32_t bi, int s_p, uint32_t q, const LimbConst &lc) {
+#pragma unroll
+    for (int k = C - 1; k >= 0; --k) {
+        const int half = 1 << (C - k - 1);
+        const uint32_t tb = (1u << (s_p + k)) + (bi << k);
+#pragma unroll
+        for (int u = 0; u < (1 << C); ++u) {
+            if (u & half) continue;
+            const uint32_t X = v[u], Y = v[u + half];
+            const uint32_t A = X + Y, D = X - Y;
+            if (LAST && k == 0) {
+                // last stage of the whole transform: |A|, |D| < 2^6 q; shift them to (0, 2^7 q) and
+                // finish with the unsigned Shoup product by N^-1 (resp. w N^-1): outputs in [0, 2q)
+                const uint32_t Ap = A + (q << 6), Dp = D + (q << 6);
+                v[u] = Ap * static_cast<uint32_t>(lc.n_inv) - __umulhi(Ap, static_cast<uint32_t>(lc.n_inv_sh)) * q;
+                v[u + half] = Dp * static_cast<uint32_t>(lc.inv_last_w) - __umulhi(Dp, static_cast<uint32_t>(lc.inv_last_w_sh)) * q;
+            } else {
+                const TwPair<uint32_t> t = tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
+                v[u] = A;
+                v[u + half] = smul_lazy(D, t.w, t.ws, q);
+            }
+        }
+    }
+}
+
+// after a pass whose inputs were all at exponent E0: fold the elements above KEEP back to exponent 1
+template <int C, int E0, int KEEP>
+__device__ __forceinline__ void gs_fold_signed(uint32_t (&v)[1 << C], uint32_t q, uint32_t mu32) {
+#pragma unroll
+    for (int u = 0; u < (1 << C); ++u)
+        if (gs_exp_from(E0, u, C - 1) > KEEP)
+            v[u] = v[u] - static_cast<uint32_t>(__mulhi(static_cast<int32_t>(v[u]), static_cast<int32_t>(mu32))) * q;
+}
+
 template <typename W, int LOGN, int LOGR, bool INV>
 struct NttLdsCfg {
     static constexpr uint32_t N = 1u << LOGN;

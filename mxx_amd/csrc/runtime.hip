@@ -206,6 +206,21 @@ static int upload_tables(GpuContext *ctx, const std::vector<std::vector<uint64_t
     HIP_TRY(hipMalloc(&ctx->d_tw2_inv, 2 * bytes));
     HIP_TRY(hipMemcpy(ctx->d_tw2_fwd, h_pf.data(), 2 * bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tw2_inv, h_pi.data(), 2 * bytes, hipMemcpyHostToDevice));
+    if (ctx->signed_ok && sizeof(W) == 4) {
+        // centred twiddle w^ in (-q/2, q/2] and w^' = floor(w^ * 2^32 / q), both as int32 bit patterns
+        auto signed_pair = [](uint64_t w, uint64_t q, W *dst) {
+            const int64_t c = w > q / 2 ? static_cast<int64_t>(w) - static_cast<int64_t>(q) : static_cast<int64_t>(w);
+            __int128 num = static_cast<__int128>(c) << 32;
+            __int128 fl = num / static_cast<__int128>(q);
+            if (num % static_cast<__int128>(q) < 0) fl -= 1;  // floor for negatives
+            dst[0] = static_cast<W>(static_cast<uint32_t>(static_cast<int32_t>(c)));
+            dst[1] = static_cast<W>(static_cast<uint32_t>(static_cast<int32_t>(fl)));
+        };
+        for (size_t l = 0; l < L; ++l)
+            for (size_t j = 0; j < N; ++j) signed_pair(inv[l][j], ctx->moduli[l], &h_pi[2 * (l * N + j)]);
+        HIP_TRY(hipMalloc(&ctx->d_tw2s_inv, 2 * bytes));
+        HIP_TRY(hipMemcpy(ctx->d_tw2s_inv, h_pi.data(), 2 * bytes, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -223,6 +238,7 @@ static void context_release(GpuContext *ctx) {
     if (ctx->d_garner) (void)hipFree(ctx->d_garner);
     if (ctx->d_tw2_fwd) (void)hipFree(ctx->d_tw2_fwd);
     if (ctx->d_tw2_inv) (void)hipFree(ctx->d_tw2_inv);
+    if (ctx->d_tw2s_inv) (void)hipFree(ctx->d_tw2s_inv);
     if (ctx->timer_start) (void)hipEventDestroy(ctx->timer_start);
     if (ctx->timer_stop) (void)hipEventDestroy(ctx->timer_stop);
     for (hipEvent_t ev : ctx->marks)
@@ -326,6 +342,7 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
     }
     ctx->crt_bits = crt_bits;
     ctx->lazy_ok = crt_bits + 7 <= (wide ? 64u : 32u);
+    ctx->signed_ok = !wide && crt_bits <= 24;  // signed lazy inverse butterflies: 2^6 q < 2^30 (ntt_lds.h)
 
     // Garner table: garner_inv[i*L + j] = (q_j)^-1 mod q_i for j < i
     // (mixed-radix CRT as the reference builds it, Runtime.cu:77-96)

@@ -96,13 +96,14 @@ def test_ntt_n16384_bench_moduli(gpu, oracle):
 
 
 def test_ntt_n16384_both_kernel_designs(gpu, oracle):
-    """grouped (ntt14.h, default) and whole-vector-in-LDS (ntt_lds.h) 2^14 kernels give identical bits."""
+    """grouped with signed butterflies (ntt14.h, default), grouped unsigned, and whole-vector-in-LDS
+    (ntt_lds.h) 2^14 kernels give identical bits."""
     n = 16384
     p = make_params(gpu, oracle, n, 4, 24, 12)
     moduli = p.moduli()
     x = rand_matrix(oracle, 6, 3, 3, moduli, n)
     want = oracle.matrix_ntt(x, moduli)
-    for design in ("grouped", "whole"):
+    for design in ("grouped", "unsigned", "whole"):
         os.environ["MXX_HIP_NTT14"] = design
         try:
             m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
@@ -112,6 +113,36 @@ def test_ntt_n16384_both_kernel_designs(gpu, oracle):
             assert np.array_equal(m.to_rns(), x), design
         finally:
             del os.environ["MXX_HIP_NTT14"]
+
+
+@pytest.mark.parametrize("bits", [24, 22, 25])
+def test_ntt_n16384_extreme_inputs(gpu, oracle, bits):
+    """Redundant-form bounds of the lazy butterflies: all residues q-1, alternating 0 / q-1 in every
+    period, a single spike - for the largest 24-bit primes (signed form), 22-bit primes, and 25-bit primes
+    (past the signed form's bound: the unsigned grouped kernels take over)."""
+    n = 16384
+    moduli = oracle.gen_crt_basis(n, 3, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 12)
+    top = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1)
+    pats = [np.broadcast_to(top, (1, 1, len(moduli), n)).copy()]
+    for period in (2, 64, 1024, 16384):
+        m = np.broadcast_to(top, (1, 1, len(moduli), n)).copy()
+        m[..., (np.arange(n) // (period // 2)) % 2 == 1] = 0
+        pats.append(m)
+    spike = np.zeros((1, 1, len(moduli), n), dtype=np.uint64)
+    spike[..., n - 1] = top[..., 0]
+    pats.append(spike)
+    x = np.concatenate(pats, axis=1)
+    want = oracle.matrix_ntt(x, moduli)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), want)
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+    # the same patterns as evaluation-domain inputs of the inverse
+    e = gpu.GpuDCRTPolyMatrix.from_rns(p, x, True)
+    e.intt_all_in_place()
+    assert np.array_equal(e.to_rns(), oracle.matrix_ntt(x, moduli, inverse=True))
 
 
 def test_ntt_n16384_u64(gpu, oracle):
