@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — ring-ops/s of the DCRT hot path on MI355X, next to the roofline and the CPU path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload m1|m2a|m2b|m3a]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload m1|m2a|m2b|m3a|m3b]
 
 Default workload = BASELINE.json configs[1] ("M1"): n=2^14, 4 RNS limbs
 (24-bit), batch of 1024 polynomials resident in HBM.  One step = one pass of the hot path
@@ -11,7 +11,9 @@ multiplications (ring-ops) by a resident EVAL-form ring element w, through the C
 Other workloads: m2a = the reference's benches/bench_matrix_mul_gpu.rs shape
 (n=2^14, L=15, (1x30)*(30x120) = 3600 ring-ops/step); m2b = 64x64 * 64x64, L=8;
 m3a = benches/bench_preimage_gpu.rs (n=2^14, L=10, sigma=4.578, d=1, 50 target columns;
-unit preimages/s).
+unit preimages/s); m3b = BASELINE.json configs[3]: the same with L=8 - with N>1 every rank samples the preimages
+of its own 50 target columns (the partition of preimage_batched_sharded) and the preimage blocks are all-gathered
+over RCCL/xGMI, the one exchange step of that configuration.
 
 N>1: one process per GPU (torch.distributed / RCCL only for the barrier and the
 max-over-ranks clock); the path shards by independent polynomials / target columns with
@@ -45,7 +47,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="m1", choices=["m1", "m2a", "m2b", "m3a"])
+    ap.add_argument("--workload", default="m1", choices=["m1", "m2a", "m2b", "m3a", "m3b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -136,7 +138,7 @@ def main():
     device = d.local_rank if d.torch is not None else 0
     n = 16384
     wl = args.workload
-    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m3a": 10}[wl]
+    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m3a": 10, "m3b": 8}[wl]
     moduli = mx.gen_crt_basis(n, depth, 24)
     params = mx.GpuDCRTPolyParams(n, moduli, 12, gpu_ids=[device])
     ctx = params.ctx()
@@ -199,12 +201,18 @@ def main():
         kernel_name = "matmul_kernel<uint32_t,...> / mmdma::kernel_u32 (R_q matrix product, EVAL)"
         algo_bytes = float(r * k + k * c + r * c) * n * L * word
         workload_desc = f"{wl.upper()}: n=2^14, L={L} (24-bit), ({r}x{k})*({k}x{c}); 1 ring-op = one R_q multiply-accumulate"
-    else:  # m3a
+    else:  # m3a / m3b
         sigma, dsize, cols = 4.578, 1, 50
         sampler = mx.GpuDCRTPolyTrapdoorSampler(params, sigma)
         td, pub = sampler.trapdoor(params, dsize)
         target = mx.GpuDCRTPolyUniformSampler().sample_uniform(params, dsize, cols, mx.DistType.FinRingDist())
         keep = {}
+        gather_full = None
+        if d.torch is not None and wl == "m3b":
+            from mxx_amd.parallel import DeviceBuffer
+
+            words = (params.modulus_digits() + 2) * dsize * cols * L * n  # one rank's preimage block
+            gather_full = d.torch.empty(d.dist.get_world_size() * words * word, dtype=d.torch.uint8, device=device)
 
         def step(i, mark):
             if mark:
@@ -212,12 +220,16 @@ def main():
             keep["x"] = sampler.preimage(params, td, pub, target)
             if mark:
                 ctx.timer_mark(2 * i + 1)
+            if gather_full is not None:
+                mx.gpu_device_sync()  # engine stream -> torch stream hand-off
+                d.dist.all_gather_into_tensor(gather_full, DeviceBuffer(keep["x"]).tensor(device))
 
         units_per_step = cols
         metric, unit = "trapdoor_preimages_per_s", "preimages/s"
         kernel_name = "preimage call (all kernels)"
         algo_bytes = None
-        workload_desc = f"M3a: bench_preimage shape n=2^14, L=10, base 2^12, sigma={sigma}, d=1, {cols} target columns"
+        workload_desc = (f"{wl.upper()}: bench_preimage shape n=2^14, L={L}, base 2^12, sigma={sigma}, d=1, {cols} target columns"
+                         + (" per rank, preimage blocks all-gathered (RCCL)" if gather_full is not None else ""))
 
     for i in range(warmup):
         step(i, False)
@@ -229,7 +241,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = d.max_over_ranks(elapsed)
 
-    if wl == "m3a":
+    if wl in ("m3a", "m3b"):
         x = keep["x"]
         assert pub * x == target, "A*x != u"
 
@@ -279,7 +291,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_desc, "ring_dim": n, "limbs": L, "limb_bits": 24,
                        "units_per_step_per_gpu": units_per_step,
-                       "sharding": ("column blocks per rank + RCCL all-gather of the product" if (wl in ("m2a", "m2b") and args.gpus > 1)
+                       "sharding": ("column blocks per rank + RCCL all-gather of the result" if (wl in ("m2a", "m2b", "m3b") and args.gpus > 1)
                                     else "independent polys / target columns per rank, no collective")},
             "roofline": roof,
             "cpu_baseline": cpu,
