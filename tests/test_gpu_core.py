@@ -465,3 +465,43 @@ def test_error_behaviour(gpu, oracle):
         gpu.GpuDCRTPolyMatrix(p, 1, 1, 5, True)  # invalid level (gpu_dcrt_poly.rs:229)
     raw = C.c_void_p()
     assert _ffi.lib().gpu_matrix_create(p.ctx_raw(), 5, 1, 1, 1, C.byref(raw)) != 0
+
+
+def test_empty_and_degenerate_shapes(gpu, oracle):
+    """0 x c, r x 0 and 1 x 1 operands through every family of entry points: no launch, no error, right
+    shapes and format tags (the reference treats zero-sized matrices as ordinary values)."""
+    n = 64
+    p = make_params(gpu, oracle, n, 2, 24, 12)
+    M = gpu.GpuDCRTPolyMatrix
+    k = p.modulus_digits()
+    for r, c in ((0, 3), (3, 0), (0, 0)):
+        z = M.zero(p, r, c)
+        assert z.size() == (r, c)
+        assert (z + z) == z and (z - z) == z
+        z2 = z.clone()
+        z2.ntt_all_in_place()
+        z2.intt_all_in_place()
+        assert z2.size() == (r, c)
+        assert z.to_rns().shape == (r, c, 2, n)
+        d = z.decompose()
+        assert d.size() == (r * k, c) and d.is_ntt
+        assert z.small_decompose().size()[1] == c
+        s = M.sample_distribution(p, r, c, oracle.DIST["gauss"], 3.0, gpu.GpuRngSeed.from_bytes(bytes(32)))
+        assert s.size() == (r, c) and s.is_ntt
+        assert z.transpose().size() == (c, r)
+        payload = z.to_compact_bytes()
+        assert M.from_compact_bytes(p, payload).size() == (r, c)
+    a = M.from_rns(p, rand_matrix(oracle, 90, 2, 3, p.moduli(), n), True)
+    assert (M.zero(p, 0, 2).ensure_eval() * a).size() == (0, 3)            # 0 x 2 times 2 x 3
+    assert (a * M.zero(p, 3, 0).ensure_eval()).size() == (2, 0)            # 2 x 3 times 3 x 0
+    inner0 = M.zero(p, 2, 0).ensure_eval() * M.zero(p, 0, 4).ensure_eval()  # empty sum: the zero matrix
+    assert inner0 == M.zero(p, 2, 4).ensure_eval()
+    assert a.slice(1, 1, 0, 3).size() == (0, 3) and a.slice(0, 2, 2, 2).size() == (2, 0)
+    assert a.concat_columns([M.zero(p, 2, 0).ensure_eval()]) == a
+    one = M.from_rns(p, rand_matrix(oracle, 91, 1, 1, p.moduli(), n), True)
+    assert np.array_equal((one * one).to_rns(), oracle.matmul(one.to_rns(), one.to_rns(), p.moduli()))
+    # zero-column preimage: the sampler returns an empty (k+2) x 0 matrix
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, 4.578)
+    td, A = sampler.trapdoor(p, 1)
+    x = sampler.preimage(p, td, A, M.zero(p, 1, 0).ensure_eval())
+    assert x.size() == (k + 2, 0)
