@@ -178,6 +178,7 @@ static int launch_ntt_typed(GpuContext *ctx, W *data, size_t vectors, uint32_t L
     const size_t N = size_t(1) << logN;
     const int force = ntt_path_override();
     const bool fits_generic = N * sizeof(W) <= kMaxLdsBytes && logN >= 1;
+    if (force == 3 || !fits_generic) return launch_global<W, INV>(ctx, data, vectors, L);  // vector larger than LDS
     if (force != 2 && ctx->lazy_ok) {
         int rc;
         if constexpr (sizeof(W) == 4) rc = launch_ntt_lds_u32(ctx, data, vectors, L, INV);

@@ -505,3 +505,44 @@ def test_empty_and_degenerate_shapes(gpu, oracle):
     td, A = sampler.trapdoor(p, 1)
     x = sampler.preimage(p, td, A, M.zero(p, 1, 0).ensure_eval())
     assert x.size() == (k + 2, 0)
+
+
+def test_maximum_limb_count(gpu, oracle):
+    """64 limbs (GPUPOLY_MAX_LIMBS, Runtime.cuh:51 of the reference): NTT, product, decompose, gadget
+    relation and the compact wire format (1280-bit coefficients through the on-device Garner CRT)."""
+    n, depth, bits, base = 16, 64, 20, 10
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    assert len(moduli) == 64
+    M = gpu.GpuDCRTPolyMatrix
+    a = rand_matrix(oracle, 95, 2, 3, moduli, n)
+    b = rand_matrix(oracle, 96, 3, 2, moduli, n)
+    ga, gb = M.from_rns(p, a, False), M.from_rns(p, b, False)
+    ga.ntt_all_in_place()
+    assert np.array_equal(ga.to_rns(), oracle.matrix_ntt(a, moduli))
+    gb.ntt_all_in_place()
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(oracle.matrix_ntt(a, moduli), oracle.matrix_ntt(b, moduli), moduli))
+    dec = M.from_rns(p, a, False).decompose()
+    assert np.array_equal(dec.to_coeff_rns(), oracle.decompose(a, moduli, base))
+    assert M.gadget_matrix(p, 2) * dec == ga
+    back = M.from_compact_bytes(p, ga.to_compact_bytes())
+    assert back == ga
+    s = M.sample_distribution(p, 1, 2, oracle.DIST["uniform"], 0.0, gpu.GpuRngSeed.from_bytes(bytes(range(32))))
+    assert np.array_equal(s.to_coeff_rns(), oracle.sample_distribution(1, 2, moduli, n, "uniform", 0.0, bytes(range(32))))
+
+
+@pytest.mark.parametrize("logn", [15, 16, 17])
+def test_ntt_large_ring_dimensions(gpu, oracle, logn):
+    """n = 2^15 (largest LDS-resident kernel), 2^16 and 2^17 (one-stage-per-launch kernels; 2^17 is the limit)."""
+    n = 1 << logn
+    moduli = oracle.gen_crt_basis(n, 2, 24)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 12)
+    x = rand_matrix(oracle, 97, 1, 2, moduli, n)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), oracle.matrix_ntt(x, moduli))
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+    y = rand_matrix(oracle, 98, 2, 1, moduli, n)
+    gy = gpu.GpuDCRTPolyMatrix.from_rns(p, y, False).ensure_eval()
+    assert np.array_equal((m.ensure_eval() * gy).to_rns(), oracle.matmul(oracle.matrix_ntt(x, moduli), oracle.matrix_ntt(y, moduli), moduli))
