@@ -53,3 +53,46 @@ def test_preimage_bench_shape_repeated(gpu, oracle):
         assert G * z == target
         x = s.preimage(p, td, A, target)
         assert A * x == target
+
+
+def test_concurrent_callers_same_context(gpu, oracle):
+    """Handles are Send + Sync on the Rust side: rayon threads call concurrently on different matrices of one
+    context and read the same const matrix.  Four host threads, one stream-ordered context."""
+    import threading
+
+    n = 4096
+    p = make_params(gpu, oracle, n, 3, 24, 12)
+    moduli = p.moduli()
+    us = gpu.GpuDCRTPolyUniformSampler()
+    shared = us.sample_uniform(p, 4, 4, gpu.DistType.FinRingDist())
+    shared_host = shared.to_rns()
+    errors = []
+
+    def worker(tid):
+        try:
+            rng = np.random.default_rng(tid)
+            for it in range(12):
+                x = np.stack([rng.integers(0, q, size=(2, 4, n), dtype=np.uint64) for q in moduli], axis=2)
+                gx = gpu.GpuDCRTPolyMatrix.from_rns(p, x, True)
+                y = gx * shared
+                want = oracle.matmul(x, shared_host, moduli, fast=True)
+                if not np.array_equal(y.to_rns(), want):
+                    errors.append((tid, it, "product"))
+                z = y.clone()
+                z.intt_all_in_place()
+                z.ntt_all_in_place()
+                if not (z == y):
+                    errors.append((tid, it, "ntt round trip"))
+                d = gx.decompose()
+                if not (gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 2) * d == gx):
+                    errors.append((tid, it, "gadget"))
+        except Exception as exc:  # surfaced below: a failing thread must fail the test
+            errors.append((tid, -1, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    assert np.array_equal(shared.to_rns(), shared_host)
