@@ -34,6 +34,7 @@ class GpuDCRTTrapdoor:
     def __init__(self, r: GpuDCRTPolyMatrix, e: GpuDCRTPolyMatrix):
         self.r = r
         self.e = e
+        self.re = r.concat_rows([e])  # [R; E], the left factor of both tp2 = [R;E] p2 and [R;E] z
         rt, et = r.transpose(), e.transpose()
         self.a_mat_coeff = _coeff_cached(r * rt)
         self.b_mat_coeff = _coeff_cached(r * et)
@@ -111,7 +112,7 @@ class GpuDCRTPolyTrapdoorSampler:
         d, dk = td.r.row_size(), td.r.col_size()
         padded = -(-total_ncol // d) * d
         p2 = u.sample_uniform(params, dk, padded, DistType.GaussDist(sigma_large))
-        tp2 = td.r.concat_rows([td.e]) * p2
+        tp2 = td.re * p2
         cache = td.p1_covariance_cache(c, s, dgg_stddev)
         p1 = GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2, random_gpu_rng_seed())
         return p1, p2
@@ -134,13 +135,13 @@ class GpuDCRTPolyTrapdoorSampler:
             p_hat_image = p_hat_image.slice_columns(0, target_cols)
         perturbed = target - p_hat_image
         z_hat = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed())
-        r_z = td.r * z_hat
+        # x = [p1 + [R;E] z ; p2 + z].  The reference forms R z and E z separately (gpu.rs:340-362); one product
+        # with the stacked factor reads the large z once - same residues.
+        re_z = td.re * z_hat
         out = GpuDCRTPolyMatrix(params, p1_rows + p2_rows, target_cols, p1.level, p1.is_ntt)
         out.copy_block_from(p1, 0, 0, 0, 0, p1_rows, target_cols)
         out.copy_block_from(p2, p1_rows, 0, 0, 0, p2_rows, target_cols)
-        out.add_block_from(r_z, 0, 0, 0, 0, r_z.row_size(), target_cols)
-        e_z = td.e * z_hat
-        out.add_block_from(e_z, d, 0, 0, 0, e_z.row_size(), target_cols)
+        out.add_block_from(re_z, 0, 0, 0, 0, re_z.row_size(), target_cols)
         out.add_block_from(z_hat, 2 * d, 0, 0, 0, z_hat.row_size(), target_cols)
         return out
 
