@@ -546,3 +546,11 @@ def test_ntt_large_ring_dimensions(gpu, oracle, logn):
     y = rand_matrix(oracle, 98, 2, 1, moduli, n)
     gy = gpu.GpuDCRTPolyMatrix.from_rns(p, y, False).ensure_eval()
     assert np.array_equal((m.ensure_eval() * gy).to_rns(), oracle.matmul(oracle.matrix_ntt(x, moduli), oracle.matrix_ntt(y, moduli), moduli))
+    # the callers of the transform at this size: decompose (EVAL in/out), Gaussian matrix, compact bytes
+    dec = gy.decompose()
+    assert np.array_equal(dec.to_coeff_rns(), oracle.decompose(y, moduli, 12))
+    assert gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 2) * dec == gy
+    sd = bytes(range(32))
+    g = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 1, 1, oracle.DIST["gauss"], 7.5, gpu.GpuRngSeed.from_bytes(sd))
+    assert np.array_equal(g.to_coeff_rns(), oracle.sample_distribution(1, 1, moduli, n, "gauss", 7.5, sd))
+    assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, gy.to_compact_bytes()) == gy
