@@ -160,6 +160,9 @@ int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, size_t *out_
 int gpupoly_context_device(const GpuContext *ctx, int *out_device);
 int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes);
 const char *gpupoly_version(void);
+/* MXX_HIP_* switches are read once, at gpu_context_create; this re-reads them for every live
+ * context of the process (tests flip them between calls).                      */
+int gpupoly_reload_env(void);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,7 @@ SIGNATURES = {
     "gpupoly_context_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_context_word_bytes": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_version": (C.c_char_p, []),
+    "gpupoly_reload_env": (C.c_int, []),
 }
 
 _lib = None
@@ -133,6 +134,11 @@ def last_error_string() -> str:
 def check_status(code: int, context: str) -> None:
     if code != 0:
         raise GpuPolyError(f"{context} failed: {last_error_string()}")
+
+
+def reload_env() -> None:
+    """Re-read the MXX_HIP_* switches (libgpupoly caches them per context at creation)."""
+    check_status(lib().gpupoly_reload_env(), "gpupoly_reload_env")
 
 
 def gpu_device_sync() -> None:

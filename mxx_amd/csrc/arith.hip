@@ -371,14 +371,14 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
     }
     {
         // MXX_HIP_MATMUL_PATH = reg | lds | dma forces a kernel family (tests cover all)
-        const char *force = std::getenv("MXX_HIP_MATMUL_PATH");
+        const char force = ctx->env.matmul_path;
         const bool lds_ok = N >= 64 && (N % 64) == 0;
-        const bool want_dma = force ? (force[0] == 'd') : (rows >= 32 && cols >= 16);
+        const bool want_dma = force ? (force == 'd') : (rows >= 32 && cols >= 16);
         if (want_dma) {
             const int rc = launch_matmul_dma_u32(out, lhs, rhs);
             if (rc >= 0) return rc;
         }
-        const bool want_lds = force ? (force[0] == 'l' || force[0] == 'd') : (rows >= 8 && cols >= 8);
+        const bool want_lds = force ? (force == 'l' || force == 'd') : (rows >= 8 && cols >= 8);
         if (lds_ok && want_lds) return launch_matmul_lds_u32(out, lhs, rhs);
     }
     if (N >= 4) {

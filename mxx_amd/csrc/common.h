@@ -32,7 +32,23 @@ struct LimbConst {
     uint32_t lazy_terms; // how many q^2-bounded products fit the accumulator
 };
 
+// Environment switches, read ONCE per context at gpu_context_create (not per launch: a preimage call
+// at n = 256 is ~30 launches and each getenv scans the environment under libc's lock).
+// gpupoly_reload_env() re-reads them for every live context (tests flip them between calls).
+struct EnvSwitches {
+    int ntt_path = 0;             // MXX_HIP_NTT_PATH: 0 auto, 1 lds, 2 generic, 3 global
+    int ntt14 = 0;                // MXX_HIP_NTT14: 0 grouped signed, 1 whole-vector kernel, 2 grouped unsigned
+    bool decompose_fused = true;  // MXX_HIP_DECOMPOSE_FUSED=0 disables digits-in-the-NTT-load
+    char matmul_path = 0;         // MXX_HIP_MATMUL_PATH: 0 auto, 'r' reg, 'l' lds, 'd' dma, 'm' mfma
+    bool gsamp_simple = false;    // MXX_HIP_GSAMP=simple
+    bool p1_simple = false;       // MXX_HIP_P1=simple
+    int sampler_per_lane = 0;     // MXX_HIP_SAMPLER_PER_LANE (0 = sized for one resident round)
+    bool mul_decompose_fused = true;  // MXX_HIP_MUL_DECOMPOSE_FUSED=0: decompose-then-multiply in column chunks
+    void load();
+};
+
 struct GpuContext {
+    EnvSwitches env;
     int device = 0;
     std::vector<int> gpu_ids;
     uint32_t logN = 0;
@@ -139,6 +155,24 @@ inline size_t matrix_words(const GpuMatrix *m) { return matrix_polys(m) * matrix
 int ctx_activate(const GpuContext *ctx);                   // hipSetDevice
 int ctx_alloc(GpuContext *ctx, size_t bytes, void **out);  // stream-ordered
 void ctx_free(GpuContext *ctx, void *ptr);                 // stream-ordered
+// a stream-ordered block that goes back to the context's cache when the scope ends (error paths
+// included) unless ownership is handed on with release()
+struct CtxBlock {
+    GpuContext *ctx;
+    void *ptr = nullptr;
+    explicit CtxBlock(GpuContext *c) : ctx(c) {}
+    CtxBlock(const CtxBlock &) = delete;
+    CtxBlock &operator=(const CtxBlock &) = delete;
+    ~CtxBlock() {
+        if (ptr) ctx_free(ctx, ptr);
+    }
+    int alloc(size_t bytes) { return ctx_alloc(ctx, bytes, &ptr); }
+    void *release() {
+        void *p = ptr;
+        ptr = nullptr;
+        return p;
+    }
+};
 int matrix_check_same_shape(const GpuMatrix *a, const GpuMatrix *b, const char *who);
 
 // internal launchers shared across translation units

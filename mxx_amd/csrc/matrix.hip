@@ -251,7 +251,7 @@ extern "C" int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, s
 }
 
 // ---- ABI: RNS batch load/store (MatrixSerde.cu:566-924 behaviour) -----------------------------
-static int make_event_set(GpuContext *ctx, GpuEventSet **out_events, void *dev_staging) {
+static int make_event_set(GpuContext *ctx, GpuEventSet **out_events) {
     GpuEventSet *set = new GpuEventSet();
     set->device = ctx->device;
     set->ctx = ctx;
@@ -269,7 +269,6 @@ static int make_event_set(GpuContext *ctx, GpuEventSet **out_events, void *dev_s
         return set_error(e, "hipEventRecord");
     }
     set->events.push_back(ev);
-    if (dev_staging) ctx_free(ctx, dev_staging);  // stream-ordered, after the kernels that read it
     if (out_events) {
         *out_events = set;
     } else {
@@ -303,8 +302,9 @@ extern "C" int gpu_matrix_load_rns_batch(GpuMatrix *mat, const uint8_t *bytes, s
     const size_t max_stage_bytes = size_t(512) << 20;
     size_t polys_per_chunk = std::max<size_t>(1, max_stage_bytes / bytes_per_poly);
     polys_per_chunk = std::min(polys_per_chunk, polys);
-    void *stage = nullptr;
-    if (ctx_alloc(ctx, polys_per_chunk * bytes_per_poly, &stage)) return 1;
+    CtxBlock stage_block(ctx);  // back to the cache at scope exit, error paths included
+    if (stage_block.alloc(polys_per_chunk * bytes_per_poly)) return 1;
+    void *const stage = stage_block.ptr;
     for (size_t p0 = 0; p0 < polys; p0 += polys_per_chunk) {
         size_t pc = std::min(polys_per_chunk, polys - p0);
         HIP_TRY(hipMemcpyAsync(stage, bytes + p0 * bytes_per_poly, pc * bytes_per_poly, hipMemcpyHostToDevice,
@@ -322,7 +322,7 @@ extern "C" int gpu_matrix_load_rns_batch(GpuMatrix *mat, const uint8_t *bytes, s
         HIP_TRY(hipGetLastError());
     }
     mat->format = format;  // "just retags" 
-    return make_event_set(ctx, out_events, stage);
+    return make_event_set(ctx, out_events);  // stage_block returns to the cache here, stream-ordered after its readers
     ABI_GUARD_END
 }
 
@@ -345,8 +345,9 @@ extern "C" int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_o
     const size_t max_stage_bytes = size_t(512) << 20;
     size_t polys_per_chunk = std::max<size_t>(1, max_stage_bytes / bytes_per_poly);
     polys_per_chunk = std::min(polys_per_chunk, polys);
-    void *stage = nullptr;
-    if (ctx_alloc(ctx, polys_per_chunk * bytes_per_poly, &stage)) return 1;
+    CtxBlock stage_block(ctx);  // back to the cache at scope exit, error paths included
+    if (stage_block.alloc(polys_per_chunk * bytes_per_poly)) return 1;
+    void *const stage = stage_block.ptr;
     if (dst_wpp != wpp) HIP_TRY(hipMemsetAsync(stage, 0, polys_per_chunk * bytes_per_poly, ctx->stream));
     for (size_t p0 = 0; p0 < polys; p0 += polys_per_chunk) {
         size_t pc = std::min(polys_per_chunk, polys - p0);
@@ -364,7 +365,7 @@ extern "C" int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_o
         HIP_TRY(hipMemcpyAsync(bytes_out + p0 * bytes_per_poly, stage, pc * bytes_per_poly, hipMemcpyDeviceToHost,
                                ctx->stream));
     }
-    return make_event_set(ctx, out_events, stage);
+    return make_event_set(ctx, out_events);  // stage_block returns to the cache here, stream-ordered after its readers
     ABI_GUARD_END
 }
 
@@ -382,9 +383,10 @@ extern "C" int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t
         return set_error("gpu_matrix_store_const_coeff_batch requires Coeff format");
     if (words_per_poly < L) return set_error("gpu_matrix_store_const_coeff_batch: words_per_poly < limb count");
     if (ctx_activate(ctx)) return 1;
-    void *stage = nullptr;
     size_t bytes = polys * words_per_poly * 8;
-    if (ctx_alloc(ctx, bytes, &stage)) return 1;
+    CtxBlock stage_block(ctx);
+    if (stage_block.alloc(bytes)) return 1;
+    void *const stage = stage_block.ptr;
     if (words_per_poly != L) HIP_TRY(hipMemsetAsync(stage, 0, bytes, ctx->stream));
     const dim3 blocks = item_grid(polys * L, 256);
     if (ctx->wide)
@@ -397,6 +399,6 @@ extern "C" int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t
                            (size_t)ctx->N, words_per_poly);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(words_out, stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    return make_event_set(ctx, out_events, stage);
+    return make_event_set(ctx, out_events);  // stage_block returns to the cache here, stream-ordered after its readers
     ABI_GUARD_END
 }

@@ -162,21 +162,11 @@ static int launch_global(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
     return 0;
 }
 
-static int ntt_path_override() {
-    // MXX_HIP_NTT_PATH = lds | generic | global  (tests exercise every path)
-    const char *env = std::getenv("MXX_HIP_NTT_PATH");
-    if (!env) return 0;
-    if (env[0] == 'l') return 1;
-    if (env[0] == 'g' && env[1] == 'e') return 2;
-    if (env[0] == 'g' && env[1] == 'l') return 3;
-    return 0;
-}
-
 template <typename W, bool INV>
 static int launch_ntt_typed(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
     const uint32_t logN = ctx->logN;
     const size_t N = size_t(1) << logN;
-    const int force = ntt_path_override();
+    const int force = ctx->env.ntt_path;  // MXX_HIP_NTT_PATH = lds | generic | global (tests exercise every path)
     const bool fits_generic = N * sizeof(W) <= kMaxLdsBytes && logN >= 1;
     if (force == 3 || !fits_generic) return launch_global<W, INV>(ctx, data, vectors, L);  // vector larger than LDS
     if (force != 2 && ctx->lazy_ok) {

@@ -15,10 +15,9 @@ int launch_ntt_lds_u32(GpuContext *ctx, uint32_t *data, size_t vectors, uint32_t
 // context / path override, the caller then runs the digit kernel and the transform separately
 int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff, size_t out_vectors, uint32_t L,
                           uint32_t src_cols, uint32_t towers, uint32_t dpt, uint32_t base_bits, size_t k) {
-    const char *env14 = std::getenv("MXX_HIP_NTT14"), *path = std::getenv("MXX_HIP_NTT_PATH");
-    const char *fuse = std::getenv("MXX_HIP_DECOMPOSE_FUSED");
-    if (ctx->logN != 14 || !ctx->lazy_ok || (env14 && env14[0] == 'w') || (path && path[0] != 'l') ||
-        (fuse && fuse[0] == '0') || out_vectors > 0x7fffffffull || k >> 32)
+    const EnvSwitches &env = ctx->env;
+    if (ctx->logN != 14 || !ctx->lazy_ok || env.ntt14 == 1 || env.ntt_path > 1 || !env.decompose_fused ||
+        out_vectors > 0x7fffffffull || k >> 32)
         return -1;
     hipLaunchKernelGGL(ntt14::fwd_digits_kernel<W>, dim3(static_cast<unsigned>(out_vectors)), dim3(ntt14::T),
                        ntt14::lds_bytes(sizeof(W)), ctx->stream, out, coeff, static_cast<const TwPair<W> *>(ctx->d_tw2_fwd),

@@ -5,8 +5,17 @@
 // (cuda/src/ChaCha.cu:104-167; keys in cuda/src/matrix/MatrixSampling.cu:239-289,
 // cuda/src/matrix/MatrixTrapdoor.cu:234-241,772-779):
 //   subkey  = HChaCha20(key = seed words (LE), nonce = domain_tag || stream2)
-//   state   = "expand 32-byte k" | subkey | counter64 = stream0 | nonce64 = stream1
-//   output  = successive ChaCha20 blocks (64-bit counter), read as 8 LE u64 words each.
+//   state   = "expand 32-byte k" | subkey | counter32 = 0 | nonce96 = (stream0, stream1)
+//   output  = successive ChaCha20 blocks (32-bit block counter), read as 8 LE u64 words each.
+// One departure from the reference, deliberate: ChaCha.cu:138-149 puts stream0 into the block
+// counter words, so block b of stream (s0, s1) is block 0 of stream (s0 + b, s1) - and stream ids
+// are consecutive everywhere (poly+1, column+1, tower+1), i.e. neighbouring polynomials, columns
+// and towers would share keystream one block apart.  Here the counter is a pure block counter and
+// the stream words live in the 96-bit nonce (RFC 8439 layout): stream0 in words 13 and 15[0:16],
+// stream1 in words 14 and 15[16:32] (48 bits each; every stream id on this path is a polynomial,
+// column, tower or coefficient index + 1).  No reference test pins keystream bytes; the
+// properties callers rely on (pure function of (seed, global index), column windows commute,
+// src/sampler/gpu.rs:292-361) are unchanged.
 // Discrete Gaussians use Karney's exact rejection sampler with the reference's
 // iteration caps (cuda/src/matrix/MatrixSampling.cu:30-147): only IEEE double
 // compare / add / mul / div / ceil are involved, so the CPU oracle reproduces the
@@ -26,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+
+#include "detmath.h"
 
 struct ChaChaRng {
     uint32_t state[16];
@@ -89,15 +100,21 @@ __host__ __device__ __forceinline__ ChaChaKey chacha_subkey(const GpuRngSeed &se
 }
 
 // ring_base: the block's LDS array of blockDim.x * 16 u64; call from every lane
+// counter / nonce words of stream (stream0, stream1), positioned at keystream block `block`
+__host__ __device__ __forceinline__ void chacha_set_stream(uint32_t (&state)[16], uint64_t stream0, uint64_t stream1,
+                                                           uint32_t block) {
+    state[12] = block;
+    state[13] = static_cast<uint32_t>(stream0);
+    state[14] = static_cast<uint32_t>(stream1);
+    state[15] = (static_cast<uint32_t>(stream0 >> 32) & 0xffffu) | (static_cast<uint32_t>(stream1 >> 32) << 16);
+}
+
 __device__ __forceinline__ void rng_init_keyed(ChaChaRng &rng, uint64_t *ring_base, const ChaChaKey &key,
                                                uint64_t stream0, uint64_t stream1) {
     rng.state[0] = 0x61707865u; rng.state[1] = 0x3320646eu; rng.state[2] = 0x79622d32u; rng.state[3] = 0x6b206574u;
 #pragma unroll
     for (int i = 0; i < 8; ++i) rng.state[4 + i] = key.w[i];
-    rng.state[12] = static_cast<uint32_t>(stream0);
-    rng.state[13] = static_cast<uint32_t>(stream0 >> 32);
-    rng.state[14] = static_cast<uint32_t>(stream1);
-    rng.state[15] = static_cast<uint32_t>(stream1 >> 32);
+    chacha_set_stream(rng.state, stream0, stream1, 0);
     rng.ring = ring_base + threadIdx.x;
     rng.ring_stride = blockDim.x;
     rng.head = 0;
@@ -109,12 +126,10 @@ __device__ __forceinline__ void rng_init(ChaChaRng &rng, uint64_t *ring_base, co
     rng_init_keyed(rng, ring_base, chacha_subkey(seed, stream2, domain_tag), stream0, stream1);
 }
 
-// Re-key an open generator to another stream of the same family; buffered words are dropped
-__device__ __forceinline__ void rng_reopen(ChaChaRng &rng, uint64_t stream0, uint64_t stream1) {
-    rng.state[12] = static_cast<uint32_t>(stream0);
-    rng.state[13] = static_cast<uint32_t>(stream0 >> 32);
-    rng.state[14] = static_cast<uint32_t>(stream1);
-    rng.state[15] = static_cast<uint32_t>(stream1 >> 32);
+// Re-key an open generator to another stream of the same family, positioned at keystream block
+// `block`; buffered words are dropped
+__device__ __forceinline__ void rng_reopen(ChaChaRng &rng, uint64_t stream0, uint64_t stream1, uint32_t block = 0) {
+    chacha_set_stream(rng.state, stream0, stream1, block);
     rng.head = rng.tail;
 }
 
@@ -135,7 +150,7 @@ __device__ __forceinline__ void rng_fill(ChaChaRng &rng) {
             rng.ring[((rng.tail + i) & (RNG_RING_WORDS - 1)) * rng.ring_stride] =
                 static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
         }
-        if (++rng.state[12] == 0) ++rng.state[13];
+        ++rng.state[12];  // 2^32 blocks = 256 GiB per stream; no stream on this path draws more than a few
         rng.tail += 8;
     }
 }
@@ -154,12 +169,12 @@ __device__ __forceinline__ double u64_to_open01(uint64_t w) {
     return u;
 }
 
-// needs 2 words
+// needs 2 words.  Box-Muller with detmath.h's log / cos(2 pi u): fixed IEEE operation sequences,
+// so the CPU restatement reproduces every normal bit for bit (sqrt is exactly rounded on both sides)
 __device__ __forceinline__ double rng_standard_normal(ChaChaRng &rng) {
-    const double two_pi = 6.283185307179586476925286766559;
     double u1 = u64_to_open01(rng_next_u64(rng));
     double u2 = u64_to_open01(rng_next_u64(rng));
-    return sqrt(-2.0 * log(u1)) * cos(two_pi * u2);
+    return sqrt(-2.0 * det_log(u1)) * det_cos2pi(u2);
 }
 
 __device__ __forceinline__ uint64_t rng_uniform_mod(ChaChaRng &rng, uint64_t q) {
@@ -311,11 +326,8 @@ static __device__ int64_t sample_integer_karney(ChaChaRng &rng, double mean, dou
 // chip when the problem is big enough (chunks are consumed dynamically inside a workgroup, so the
 // only imbalance left is the last element of each lane).  MXX_HIP_SAMPLER_PER_LANE=n forces n
 // elements per lane (tests use it to exercise stream switching at small sizes).
-static inline uint32_t sampler_per_lane(size_t total, const void *kernel, int device) {
-    if (const char *env = std::getenv("MXX_HIP_SAMPLER_PER_LANE")) {
-        const int v = std::atoi(env);
-        if (v >= 1 && v <= 4096) return static_cast<uint32_t>(v);
-    }
+static inline uint32_t sampler_per_lane(size_t total, const void *kernel, int device, int forced) {
+    if (forced >= 1) return static_cast<uint32_t>(forced);
     int blocks_per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) != hipSuccess || blocks_per_cu < 1)
         blocks_per_cu = 2;

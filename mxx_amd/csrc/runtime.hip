@@ -96,6 +96,35 @@ static inline uint32_t h_bitrev(uint32_t x, uint32_t bits) {
 }
 static inline uint32_t h_bits(uint64_t v) { return v ? 64 - (uint32_t)__builtin_clzll(v) : 0; }
 
+// ---- environment switches + registry of live contexts -----------------------------------
+void EnvSwitches::load() {
+    *this = EnvSwitches();
+    if (const char *e = std::getenv("MXX_HIP_NTT_PATH")) {  // lds | generic | global
+        if (e[0] == 'l') ntt_path = 1;
+        else if (e[0] == 'g' && e[1] == 'e') ntt_path = 2;
+        else if (e[0] == 'g' && e[1] == 'l') ntt_path = 3;
+    }
+    if (const char *e = std::getenv("MXX_HIP_NTT14")) ntt14 = e[0] == 'w' ? 1 : (e[0] == 'u' ? 2 : 0);
+    if (const char *e = std::getenv("MXX_HIP_DECOMPOSE_FUSED")) decompose_fused = e[0] != '0';
+    if (const char *e = std::getenv("MXX_HIP_MUL_DECOMPOSE_FUSED")) mul_decompose_fused = e[0] != '0';
+    if (const char *e = std::getenv("MXX_HIP_MATMUL_PATH")) matmul_path = e[0];
+    if (const char *e = std::getenv("MXX_HIP_GSAMP")) gsamp_simple = e[0] == 's';
+    if (const char *e = std::getenv("MXX_HIP_P1")) p1_simple = e[0] == 's';
+    if (const char *e = std::getenv("MXX_HIP_SAMPLER_PER_LANE")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 4096) sampler_per_lane = v;
+    }
+}
+
+static std::mutex g_registry_mutex;
+static std::vector<GpuContext *> g_contexts;  // every live context of the process
+
+extern "C" int gpupoly_reload_env(void) {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    for (GpuContext *c : g_contexts) c->env.load();
+    return 0;
+}
+
 // ---- context ----------------------------------------------------------------------
 int ctx_activate(const GpuContext *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
@@ -138,9 +167,25 @@ int ctx_alloc(GpuContext *ctx, size_t bytes, void **out) {
         return 0;
     }
     hipError_t e = hipMalloc(out, want);
-    if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+    if (e != hipSuccess) {  // out of memory: drop this context's cache and retry
         (void)hipGetLastError();
         cache_trim(ctx, 0);
+        e = hipMalloc(out, want);
+    }
+    if (e != hipSuccess) {
+        // still out of memory: other contexts on the same device (tests create many; bench N>1 shares
+        // the card with torch / RCCL) may be sitting on cached blocks - drop those too.  try_lock, so
+        // two contexts trimming each other cannot deadlock (we hold our own alloc_mutex).
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> reg(g_registry_mutex);
+            for (GpuContext *other : g_contexts) {
+                if (other == ctx || other->device != ctx->device) continue;
+                if (!other->alloc_mutex.try_lock()) continue;
+                cache_trim(other, 0);
+                other->alloc_mutex.unlock();
+            }
+        }
         e = hipMalloc(out, want);
         if (e != hipSuccess) {
             *out = nullptr;
@@ -226,6 +271,10 @@ static int upload_tables(GpuContext *ctx, const std::vector<std::vector<uint64_t
 
 static void context_release(GpuContext *ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> reg(g_registry_mutex);
+        g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), ctx), g_contexts.end());
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
@@ -293,9 +342,16 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return set_error(e, "hipStreamCreate"); }
 
+    ctx->env.load();
     {
         ctx->pool_ok = true;
-        ctx->cache_limit = size_t(192) << 30;
+        // default cap on cached (freed, reusable) bytes: half of what the device has free now, so that
+        // several contexts, torch and RCCL on one card do not starve each other; an allocation that
+        // still fails trims every context's cache on the device before giving up (ctx_alloc)
+        size_t free_b = 0, total_b = 0;
+        ctx->cache_limit = size_t(64) << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) ctx->cache_limit = free_b / 2;
+        else (void)hipGetLastError();
         const char *env = std::getenv("MXX_HIP_MEMPOOL_RELEASE_THRESHOLD_BYTES");
         if (!env) env = std::getenv("MXX_CUDA_MEMPOOL_RELEASE_THRESHOLD_BYTES");
         if (env && *env) ctx->cache_limit = std::strtoull(env, nullptr, 10);
@@ -333,8 +389,10 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
         lc.inv_last_w = h_mulmod(inv[l][1 % N], lc.n_inv, q);
         lc.inv_last_w_sh = static_cast<uint64_t>(((u128h)lc.inv_last_w << (wide ? 64 : 32)) / q);
         if (!wide) {
+            // the accumulator carries a folded residue (< q) into every window of products:
+            // (q - 1) + terms * (q - 1)^2 must stay below 2^64
             u128h q2 = (u128h)(q - 1) * (q - 1);
-            u128h terms = ((((u128h)1) << 64) - 1) / q2;
+            u128h terms = ((((u128h)1) << 64) - q) / q2;
             lc.lazy_terms = terms > (1u << 20) ? (1u << 20) : static_cast<uint32_t>(terms);
         } else {
             lc.lazy_terms = 1;
@@ -371,6 +429,10 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
         context_release(ctx);
         g_last_error = keep;
         return rc;
+    }
+    {
+        std::lock_guard<std::mutex> reg(g_registry_mutex);
+        g_contexts.push_back(ctx);
     }
     *out_ctx = ctx;
     return 0;

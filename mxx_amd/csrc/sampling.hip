@@ -128,7 +128,7 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
     if (dist == GPU_MATRIX_DIST_GAUSS) {
         // enough lanes to fill the chip first, then up to 16 coefficients per lane
         if (polys >> 32) return set_error("gpu_matrix_sample_distribution: too many polynomials");
-        const uint32_t per_lane = sampler_per_lane(total, reinterpret_cast<const void *>(sample_gauss_kernel), ctx->device);
+        const uint32_t per_lane = sampler_per_lane(total, reinterpret_cast<const void *>(sample_gauss_kernel), ctx->device, ctx->env.sampler_per_lane);
         const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
         const KarneyDivisor div = karney_divisor(sigma);
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);

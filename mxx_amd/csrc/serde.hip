@@ -218,8 +218,9 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     const size_t coeffs = polys * N;
     const dim3 blocks = item_grid(coeffs, 256);
     const size_t gstride = static_cast<size_t>(ctx->limb_count);
-    void *d_max = nullptr;
-    if (ctx_alloc(ctx, sizeof(unsigned int), &d_max)) return 1;
+    CtxBlock max_block(ctx);
+    if (max_block.alloc(sizeof(unsigned int))) return 1;
+    void *const d_max = max_block.ptr;
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned int), ctx->stream));
     if (ctx->wide)
         hipLaunchKernelGGL(compact_maxbits_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
@@ -233,7 +234,6 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     unsigned int h_max = 0;
     HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx_free(ctx, d_max);
     const unsigned int width = h_max == 0 ? 0 : h_max + 1;
     if (width > 0xffffu) return set_error("centered max coeff bits exceed u16 range in gpu_matrix_store_compact_bytes");
     const unsigned int bytes_per_coeff = (width + 7) / 8;
@@ -243,8 +243,9 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     if (payload_len > 0) {
         if (!payload_out) return set_error("null payload buffer in gpu_matrix_store_compact_bytes");
         const size_t padded = (payload_len + 3) / 4 * 4 + 4;
-        void *d_payload = nullptr;
-        if (ctx_alloc(ctx, padded, &d_payload)) return 1;
+        CtxBlock payload_block(ctx);
+        if (payload_block.alloc(padded)) return 1;
+        void *const d_payload = payload_block.ptr;
         HIP_TRY(hipMemsetAsync(d_payload, 0, padded, ctx->stream));
         if (ctx->wide)
             hipLaunchKernelGGL(compact_pack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
@@ -257,7 +258,6 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(payload_out, d_payload, payload_len, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        ctx_free(ctx, d_payload);
     }
     *out_max_coeff_bits = static_cast<uint16_t>(width);
     *out_bytes_per_coeff = static_cast<uint16_t>(bytes_per_coeff);
@@ -286,11 +286,12 @@ extern "C" int gpu_matrix_load_compact_bytes(GpuMatrix *mat, const uint8_t *payl
     if (ctx_activate(ctx)) return 1;
     SerdeConsts sc;
     if (build_consts(mat, sc)) return 1;
-    void *d_payload = nullptr;
+    CtxBlock payload_block(ctx);
     if (payload_len) {
-        if (ctx_alloc(ctx, payload_len, &d_payload)) return 1;
-        HIP_TRY(hipMemcpyAsync(d_payload, payload, payload_len, hipMemcpyHostToDevice, ctx->stream));
+        if (payload_block.alloc(payload_len)) return 1;
+        HIP_TRY(hipMemcpyAsync(payload_block.ptr, payload, payload_len, hipMemcpyHostToDevice, ctx->stream));
     }
+    void *const d_payload = payload_block.ptr;
     const dim3 blocks = item_grid(coeffs, 256);
     if (ctx->wide)
         hipLaunchKernelGGL(compact_unpack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
@@ -302,7 +303,6 @@ extern "C" int gpu_matrix_load_compact_bytes(GpuMatrix *mat, const uint8_t *payl
                            static_cast<uint32_t>(max_coeff_bits));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // synchronous, like the reference; payload may be freed by the caller
-    if (d_payload) ctx_free(ctx, d_payload);
     return 0;
     ABI_GUARD_END
 }

@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
 #pragma unroll
                         for (int w = 0; w < 8; ++w) rng.state[4 + w] = key.w[w];
                         // block 0 went to pass 1: take its unused words, continue at block 1
-                        rng_reopen(rng, static_cast<uint64_t>(t) + 2, static_cast<uint64_t>(p) + 1);
+                        rng_reopen(rng, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1, 1);
                         for (uint32_t w = 0; w < nleft; ++w)
                             rng.ring[((rng.tail + w) & (RNG_RING_WORDS - 1)) * rng.ring_stride] = left_in[static_cast<size_t>(w) * total + idx];
                         rng.tail += nleft;
@@ -403,7 +403,7 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
                        ctx->stream, a_words, left_words, src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys), total, L,
                        ctx->logN, dpt, base_bits, c);
     const uint32_t per_lane =
-        sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device);
+        sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device, ctx->env.sampler_per_lane);
     const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     hipLaunchKernelGGL((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
@@ -427,8 +427,7 @@ static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys
                              uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
     const size_t total = polys * L * static_cast<size_t>(ctx->N);
     // MXX_HIP_GSAMP=simple keeps the one-thread-per-element kernel for every dpt (A/B runs, tests)
-    const char *mode = std::getenv("MXX_HIP_GSAMP");
-    const bool simple = mode && mode[0] == 's';
+    const bool simple = ctx->env.gsamp_simple;
     if (!simple && dpt <= 2) return launch_gauss_samp_lanes<W, 2>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
     if (!simple && dpt <= 4) return launch_gauss_samp_lanes<W, 4>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
     const dim3 blocks = item_grid(total, 128);
@@ -727,7 +726,14 @@ extern "C" int gpu_matrix_create_p1_covariance_cache(const GpuMatrix *a_mat, con
     cache->sqrt_var = static_cast<double *>(sv);
     cache->update_coeff = static_cast<double *>(uc);
     cache->karney_div = kd;
-    HIP_TRY(hipMemsetAsync(uc, 0, n * m * m * sizeof(double), ctx->stream));
+    {
+        const hipError_t me = hipMemsetAsync(uc, 0, n * m * m * sizeof(double), ctx->stream);
+        if (me != hipSuccess) {
+            ctx_free(ctx, cov_ws);
+            gpu_matrix_destroy_p1_covariance_cache(cache);
+            return set_error(me, "hipMemsetAsync");
+        }
+    }
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(a_mat));
     const unsigned blocks = static_cast<unsigned>((n + 127) / 128);
     if (ctx->wide)
@@ -788,15 +794,14 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(out)), N = static_cast<uint32_t>(ctx->N);
     const size_t total = cols * static_cast<size_t>(N);
     // MXX_HIP_P1=simple keeps the one-thread-per-element kernel for every m (A/B runs, tests)
-    const char *mode = std::getenv("MXX_HIP_P1");
-    if (m <= 4 && !(mode && mode[0] == 's')) {
+    if (m <= 4 && !ctx->env.p1_simple) {
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * m * sizeof(int64_t), &stage)) return 1;
         const ChaChaKey key = chacha_subkey(seed, 0, kTagP1);
 #define LAUNCH_P1L(WT, MAXM)                                                                                      \
     do {                                                                                                          \
         const uint32_t per_lane =                                                                                 \
-            sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM>), ctx->device); \
+            sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM>), ctx->device, ctx->env.sampler_per_lane); \
         const unsigned lblocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));        \
         hipLaunchKernelGGL((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(256), 0, ctx->stream,          \
                            static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,    \

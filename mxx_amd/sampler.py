@@ -43,9 +43,34 @@ class DistType:
         }[self.kind]
 
 
+_seed_source = None  # test-only hook: a callable returning 32 bytes per draw (see seed_source)
+
+
 def random_gpu_rng_seed() -> GpuRngSeed:
     """OS randomness, as the reference (src/sampler/gpu.rs:138-142)."""
+    if _seed_source is not None:
+        return GpuRngSeed.from_bytes(_seed_source())
     return GpuRngSeed.from_bytes(os.urandom(32))
+
+
+class seed_source:
+    """Test-only: `with seed_source(iterable_of_32_byte_seeds):` makes every seed the samplers would
+    draw from the OS come from the iterable instead, in call order, so a whole trapdoor / preimage
+    chain can be replayed against the CPU restatement.  Not thread-safe; production code never sets it."""
+
+    def __init__(self, seeds):
+        self._it = iter(seeds)
+
+    def __enter__(self):
+        global _seed_source
+        self._prev = _seed_source
+        _seed_source = lambda: next(self._it)
+        return self
+
+    def __exit__(self, *exc):
+        global _seed_source
+        _seed_source = self._prev
+        return False
 
 
 def hash_seed_for_matrix(key: bytes, tag: bytes, hash_name: str = "sha3_256") -> GpuRngSeed:

@@ -23,10 +23,11 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle_sampling.c")]
+    deps = srcs + [os.path.join(_HERE, "..", "mxx_amd", "csrc", "detmath.h")]  # Box-Muller's log / cos, shared text
     if (
         force
         or not os.path.exists(_LIB_PATH)
-        or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+        or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in deps)
     ):
         subprocess.check_call(
             ["gcc", "-O3", "-fopenmp", "-fPIC", "-std=gnu11", "-ffp-contract=off", "-shared", "-o", _LIB_PATH]
@@ -434,9 +435,13 @@ def preimage(moduli, n: int, base_bits: int, sigma: float, r, e, a, target, seed
         cov = p1_covariance(inv(matmul(r, rt, moduli, fast=True)), inv(matmul(r, et, moduli, fast=True)),
                             inv(matmul(e, et, moduli, fast=True)), moduli, c, s, sigma)
     sv, up = cov
-    p2 = matrix_ntt(sample_distribution(dk, cols, moduli, n, "gauss", math.sqrt(s * s - c * c), _seed_from(seed, 3)), moduli)
+    # the perturbation is sampled for ceil(cols / d) * d columns and cut back (gpu.rs:436-438, 288-292):
+    # the padding changes the global polynomial indices the streams are keyed by
+    padded = -(-cols // d) * d
+    p2 = matrix_ntt(sample_distribution(dk, padded, moduli, n, "gauss", math.sqrt(s * s - c * c), _seed_from(seed, 3)), moduli)
     tp2 = matrix_ntt(matmul(re, p2, moduli, fast=True), moduli, inverse=True)
     p1 = matrix_ntt(sample_p1(tp2, moduli, sv, up, -(c * c) / (s * s - c * c), _seed_from(seed, 4)), moduli)
+    p1, p2 = p1[:, :cols], p2[:, :cols]
     p_hat = pointwise("add", matmul(a[:, : 2 * d], p1, moduli, fast=True), matmul(a[:, 2 * d :], p2, moduli, fast=True), moduli)
     pert = matrix_ntt(pointwise("sub", target, p_hat, moduli), moduli, inverse=True)
     z = matrix_ntt(gauss_samp_gq(pert, moduli, base_bits, c, _seed_from(seed, 5)), moduli)

@@ -10,8 +10,10 @@
  * The reference's CPU path draws from OpenFHE's generators with OS entropy and is not
  * reproducible; what IS specified in-tree is the device sampler, which this file
  * restates (paths relative to /root/reference):
- *   - stream keying: HChaCha20 sub-key from (seed, domain tag, stream2), 64-bit block
- *     counter = stream0, nonce = stream1                 cuda/src/ChaCha.cu:104-167
+ *   - stream keying: HChaCha20 sub-key from (seed, domain tag, stream2) as in
+ *     cuda/src/ChaCha.cu:104-167; block counter starts at 0 and (stream0, stream1) form the
+ *     96-bit nonce (the reference's counter = stream0 lets adjacent streams share keystream;
+ *     mxx_amd/csrc/rng.h states the layout)
  *   - uniform-mod rejection, bit, ternary, Karney's exact discrete Gaussian with the
  *     reference's iteration caps                  cuda/src/matrix/MatrixSampling.cu:6-330
  *   - G-lattice sampler (Genise-Micciancio, arbitrary base)
@@ -25,6 +27,12 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* Box-Muller's log / cos as fixed IEEE operation sequences: the same text the device compiles */
+#include "../mxx_amd/csrc/detmath.h"
+
+double orc_det_log(double x) { return det_log(x); }
+double orc_det_cos2pi(double u) { return det_cos2pi(u); }
 
 typedef struct {
     uint32_t state[16];
@@ -66,15 +74,18 @@ static void rng_init(rng_t *r, const uint64_t seed[4], uint64_t s0, uint64_t s1,
     r->state[0] = 0x61707865u; r->state[1] = 0x3320646eu; r->state[2] = 0x79622d32u; r->state[3] = 0x6b206574u;
     r->state[4] = x[0]; r->state[5] = x[1]; r->state[6] = x[2]; r->state[7] = x[3];
     r->state[8] = x[12]; r->state[9] = x[13]; r->state[10] = x[14]; r->state[11] = x[15];
-    r->state[12] = (uint32_t)s0; r->state[13] = (uint32_t)(s0 >> 32);
-    r->state[14] = (uint32_t)s1; r->state[15] = (uint32_t)(s1 >> 32);
+    /* pure 32-bit block counter; the stream words live in the 96-bit nonce (rng.h explains the
+       departure from cuda/src/ChaCha.cu:138-149, whose counter = stream0 makes adjacent streams overlap) */
+    r->state[12] = 0; r->state[13] = (uint32_t)s0;
+    r->state[14] = (uint32_t)s1;
+    r->state[15] = ((uint32_t)(s0 >> 32) & 0xffffu) | ((uint32_t)(s1 >> 32) << 16);
     r->pos = 8;
 }
 
 static uint64_t rng_u64(rng_t *r) {
     if (r->pos >= 8) {
         orc_chacha20_block(r->state, r->block);
-        if (++r->state[12] == 0) ++r->state[13];
+        ++r->state[12];
         r->pos = 0;
     }
     uint64_t v = (uint64_t)r->block[2 * r->pos] | ((uint64_t)r->block[2 * r->pos + 1] << 32);
@@ -98,9 +109,8 @@ static double u01(rng_t *r) {
 }
 
 static double std_normal(rng_t *r) {
-    const double two_pi = 6.283185307179586476925286766559;
     double u1 = u01(r), u2 = u01(r);
-    return sqrt(-2.0 * log(u1)) * cos(two_pi * u2);
+    return sqrt(-2.0 * det_log(u1)) * det_cos2pi(u2);
 }
 
 static uint64_t uniform_mod(rng_t *r, uint64_t q) {

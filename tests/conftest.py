@@ -22,9 +22,42 @@ def _gpu_available() -> bool:
         return False
 
 
-def pytest_collection_modifyitems(config, items):
-    # -m gpu on a GPU-less box: fail loudly rather than silently pass on a fallback
-    pass
+class _HipEnv:
+    """MXX_HIP_* switches are cached per context at creation: set / unset + gpupoly_reload_env."""
+
+    def __init__(self):
+        self._saved = {}
+
+    def _reload(self):
+        from mxx_amd import _ffi
+
+        _ffi.reload_env()
+
+    def set(self, name, value):
+        self._saved.setdefault(name, os.environ.get(name))
+        os.environ[name] = value
+        self._reload()
+
+    def unset(self, name):
+        self._saved.setdefault(name, os.environ.get(name))
+        os.environ.pop(name, None)
+        self._reload()
+
+    def restore(self):
+        for name, old in self._saved.items():
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+        self._saved.clear()
+        self._reload()
+
+
+@pytest.fixture
+def hip_env():
+    env = _HipEnv()
+    yield env
+    env.restore()
 
 
 @pytest.fixture(scope="session")

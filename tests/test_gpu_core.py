@@ -67,19 +67,16 @@ def test_ntt_intt_vs_oracle(gpu, oracle, n, depth, bits, base):
 
 @pytest.mark.parametrize("path", ["generic", "global"])
 @pytest.mark.parametrize("n,depth,bits,base", [(128, 2, 17, 1), (1024, 3, 24, 12), (1024, 5, 51, 17)])
-def test_ntt_alternate_kernels(gpu, oracle, path, n, depth, bits, base):
+def test_ntt_alternate_kernels(gpu, oracle, hip_env, path, n, depth, bits, base):
     p = make_params(gpu, oracle, n, depth, bits, base)
     moduli = p.moduli()
     x = rand_matrix(oracle, 3, 1, 3, moduli, n)
-    os.environ["MXX_HIP_NTT_PATH"] = path
-    try:
-        m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
-        m.ntt_all_in_place()
-        assert np.array_equal(m.to_rns(), oracle.matrix_ntt(x, moduli))
-        m.intt_all_in_place()
-        assert np.array_equal(m.to_rns(), x)
-    finally:
-        del os.environ["MXX_HIP_NTT_PATH"]
+    hip_env.set("MXX_HIP_NTT_PATH", path)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), oracle.matrix_ntt(x, moduli))
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
 
 
 def test_ntt_n16384_bench_moduli(gpu, oracle):
@@ -95,7 +92,7 @@ def test_ntt_n16384_bench_moduli(gpu, oracle):
     assert np.array_equal(m.to_rns(), x)
 
 
-def test_ntt_n16384_both_kernel_designs(gpu, oracle):
+def test_ntt_n16384_both_kernel_designs(gpu, oracle, hip_env):
     """grouped with signed butterflies (ntt14.h, default), grouped unsigned, and whole-vector-in-LDS
     (ntt_lds.h) 2^14 kernels give identical bits."""
     n = 16384
@@ -104,15 +101,12 @@ def test_ntt_n16384_both_kernel_designs(gpu, oracle):
     x = rand_matrix(oracle, 6, 3, 3, moduli, n)
     want = oracle.matrix_ntt(x, moduli)
     for design in ("grouped", "unsigned", "whole"):
-        os.environ["MXX_HIP_NTT14"] = design
-        try:
-            m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
-            m.ntt_all_in_place()
-            assert np.array_equal(m.to_rns(), want), design
-            m.intt_all_in_place()
-            assert np.array_equal(m.to_rns(), x), design
-        finally:
-            del os.environ["MXX_HIP_NTT14"]
+        hip_env.set("MXX_HIP_NTT14", design)
+        m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+        m.ntt_all_in_place()
+        assert np.array_equal(m.to_rns(), want), design
+        m.intt_all_in_place()
+        assert np.array_equal(m.to_rns(), x), design
 
 
 @pytest.mark.parametrize("bits", [24, 22, 25])
@@ -195,7 +189,7 @@ def test_matmul_vs_oracle(gpu, oracle, shape, n, depth, bits, base):
 
 @pytest.mark.parametrize("path", ["reg", "lds"])
 @pytest.mark.parametrize("shape", [(8, 8, 8), (9, 5, 17), (16, 16, 16), (20, 7, 33), (1, 6, 40), (33, 3, 9)])
-def test_matmul_kernel_families(gpu, oracle, path, shape):
+def test_matmul_kernel_families(gpu, oracle, hip_env, path, shape):
     """register-tiled and LDS-tiled products agree with the oracle on ragged shapes (n >= 64)."""
     r, k, c = shape
     n = 128
@@ -205,16 +199,13 @@ def test_matmul_kernel_families(gpu, oracle, path, shape):
     b = rand_matrix(oracle, 26, k, c, moduli, n)
     ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
     gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
-    os.environ["MXX_HIP_MATMUL_PATH"] = path
-    try:
-        assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
-    finally:
-        del os.environ["MXX_HIP_MATMUL_PATH"]
+    hip_env.set("MXX_HIP_MATMUL_PATH", path)
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
 
 
 @pytest.mark.parametrize("shape", [(32, 8, 16), (33, 12, 17), (64, 64, 64), (16, 4, 8), (40, 36, 5), (3, 16, 70)])
 @pytest.mark.parametrize("bits", [24, 31])
-def test_matmul_dma_kernel(gpu, oracle, monkeypatch, shape, bits):
+def test_matmul_dma_kernel(gpu, oracle, hip_env, shape, bits):
     """global->LDS streamed product (matmul_dma.hip): full and ragged 32x16 tiles, inner % 4 == 0, and
     31-bit primes whose accumulators must be folded every chunk; worst-case residues q-1 in one operand."""
     r, k, c = shape
@@ -226,7 +217,7 @@ def test_matmul_dma_kernel(gpu, oracle, monkeypatch, shape, bits):
     b[::2] = rand_matrix(oracle, 28, k, c, moduli, n)[::2]
     ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
     gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
-    monkeypatch.setenv("MXX_HIP_MATMUL_PATH", "dma")
+    hip_env.set("MXX_HIP_MATMUL_PATH", "dma")
     assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
 
 
@@ -317,7 +308,7 @@ def test_decompose_and_gadget(gpu, oracle, n, depth, bits, base):
 
 
 @pytest.mark.parametrize("depth,bits,base", [(3, 24, 12), (2, 24, 7), (2, 20, 20)])
-def test_decompose_fused_with_ntt_at_2_14(gpu, oracle, monkeypatch, depth, bits, base):
+def test_decompose_fused_with_ntt_at_2_14(gpu, oracle, hip_env, depth, bits, base):
     """n = 2^14 takes the fused digit + forward-NTT kernel (ntt14.h); it must give the bits of the
     two-step path and of the CPU restatement (digit layout, last-digit mask, small variant)."""
     n = 16384
@@ -331,7 +322,7 @@ def test_decompose_fused_with_ntt_at_2_14(gpu, oracle, monkeypatch, depth, bits,
     assert gm.ensure_eval().decompose() == fused  # EVAL source: private INTT copy feeds the fused kernel
     small = gm.small_decompose()
     assert np.array_equal(small.to_rns(), oracle.matrix_ntt(oracle.decompose(M, moduli, base, small=True), moduli))
-    monkeypatch.setenv("MXX_HIP_DECOMPOSE_FUSED", "0")
+    hip_env.set("MXX_HIP_DECOMPOSE_FUSED", "0")
     assert gm.decompose() == fused and gm.small_decompose() == small
     G = gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 2)
     assert G * fused == gm.ensure_eval()

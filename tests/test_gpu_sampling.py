@@ -46,10 +46,10 @@ def test_sample_distribution_bit_exact(gpu, oracle, n, depth, bits, base, dist, 
 
 @pytest.mark.parametrize("per_lane", ["1", "3", "16"])
 @pytest.mark.parametrize("n,rows,cols,sigma", [(128, 2, 3, 4.578), (1024, 1, 5, 8191.5)])
-def test_gauss_persistent_lanes_bit_exact(gpu, oracle, monkeypatch, per_lane, n, rows, cols, sigma):
+def test_gauss_persistent_lanes_bit_exact(gpu, oracle, hip_env, per_lane, n, rows, cols, sigma):
     """Lanes that work through several coefficients (stream switch, parked states, idle tails)
     still produce the sequential sampler's integers."""
-    monkeypatch.setenv("MXX_HIP_SAMPLER_PER_LANE", per_lane)
+    hip_env.set("MXX_HIP_SAMPLER_PER_LANE", per_lane)
     p = make_params(gpu, oracle, n, 2, 24, 12)
     s = seed(gpu, 9)
     m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, rows, cols, oracle.DIST["gauss"], sigma, s)
@@ -59,17 +59,17 @@ def test_gauss_persistent_lanes_bit_exact(gpu, oracle, monkeypatch, per_lane, n,
 
 @pytest.mark.parametrize("per_lane", ["1", "5"])
 @pytest.mark.parametrize("n,depth,bits,base", [(1024, 2, 24, 12), (128, 2, 17, 6), (64, 2, 51, 17), (128, 2, 16, 16)])
-def test_gauss_samp_gq_lane_form_equals_simple_form(gpu, oracle, monkeypatch, per_lane, n, depth, bits, base):
+def test_gauss_samp_gq_lane_form_equals_simple_form(gpu, oracle, hip_env, per_lane, n, depth, bits, base):
     """The two-pass persistent-lane G-sampler and the one-thread-per-element kernel consume the
     same streams in the same order: identical digits (dpt = 2, 3, 3, 1)."""
     p = make_params(gpu, oracle, n, depth, bits, base)
     M = rand_matrix(oracle, 123, 2, 3, p.moduli(), n)
     c = ((1 << base) + 1) * 4.578
     s = seed(gpu, 11)
-    monkeypatch.setenv("MXX_HIP_SAMPLER_PER_LANE", per_lane)
-    monkeypatch.delenv("MXX_HIP_GSAMP", raising=False)
+    hip_env.set("MXX_HIP_SAMPLER_PER_LANE", per_lane)
+    hip_env.unset("MXX_HIP_GSAMP")
     z_lanes = gpu.GpuDCRTPolyMatrix.from_rns(p, M, False).gauss_samp_gq_arb_base(c, 4.578, s)
-    monkeypatch.setenv("MXX_HIP_GSAMP", "simple")
+    hip_env.set("MXX_HIP_GSAMP", "simple")
     z_simple = gpu.GpuDCRTPolyMatrix.from_rns(p, M, False).gauss_samp_gq_arb_base(c, 4.578, s)
     assert z_lanes == z_simple
     if bits > base:  # one digit per tower: the reference's formula (MatrixTrapdoor.cu:811-814) adds base*z, so
@@ -118,28 +118,54 @@ def test_gauss_samp_gq_relation(gpu, oracle, n, depth, bits, base):
             assert np.array_equal(oracle.centered(zr[:, :, l], q), zc)
 
 
-def test_gauss_samp_gq_statistically_matches_oracle(gpu, oracle):
-    """Same algorithm, same streams: digit statistics agree with the CPU restatement."""
-    n, base = 1024, 12
-    p = make_params(gpu, oracle, n, 2, 24, base)
+@pytest.mark.parametrize("n,depth,bits,base,form", [
+    (1024, 2, 24, 12, "lanes"), (1024, 2, 24, 12, "simple"), (128, 2, 17, 6, "lanes"), (64, 2, 51, 17, "lanes"),
+    (128, 2, 16, 2, "simple"),  # dpt = 8: the one-thread-per-element kernel
+])
+def test_gauss_samp_gq_bit_exact(gpu, oracle, hip_env, n, depth, bits, base, form):
+    """Same algorithm, same streams, and Box-Muller's log / cos are fixed IEEE operation sequences
+    compiled into both sides (mxx_amd/csrc/detmath.h): every digit equals the CPU restatement's."""
+    p = make_params(gpu, oracle, n, depth, bits, base)
     moduli = p.moduli()
-    M = rand_matrix(oracle, 90, 1, 2, moduli, n)
+    M = rand_matrix(oracle, 90, 2, 2, moduli, n)
     c = ((1 << base) + 1) * 4.578
     s = seed(gpu, 5)
+    if form == "simple":
+        hip_env.set("MXX_HIP_GSAMP", "simple")
     z_gpu = gpu.GpuDCRTPolyMatrix.from_rns(p, M, False).gauss_samp_gq_arb_base(c, 4.578, s).to_coeff_rns()
-    z_cpu = oracle.gauss_samp_gq(M, moduli, base, c, s)
-    a = oracle.centered(z_gpu[:, :, 0], moduli[0]).astype(np.float64)
-    b = oracle.centered(z_cpu[:, :, 0], moduli[0]).astype(np.float64)
-    # transcendental functions differ by ulps only: almost every sample is identical
-    assert (a == b).mean() > 0.999
-    assert abs(a.std() / b.std() - 1) < 0.02
+    assert np.array_equal(z_gpu, oracle.gauss_samp_gq(M, moduli, base, c, s))
+
+
+@pytest.mark.parametrize("n,depth,bits,base,d,cols", [(256, 2, 24, 12, 1, 3), (64, 2, 51, 17, 2, 2), (128, 2, 16, 4, 2, 3)])
+def test_whole_preimage_replays_on_the_cpu(gpu, oracle, n, depth, bits, base, d, cols):
+    """Trapdoor generation and a preimage call with the OS seeds replaced by fixed ones (the test-only
+    hook mxx_amd.sampler.seed_source): R, E, A and the preimage x are bit-identical to the CPU chain
+    oracle.trapdoor_gen / oracle.preimage (restating src/sampler/trapdoor/gpu.rs:202-369)."""
+    from mxx_amd.sampler import seed_source
+
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    sigma = 4.578
+    master = bytes(range(32))
+    seeds = [oracle._seed_from(master, i).tobytes() for i in range(6)]  # r, e, a_bar | p2, p1, z
+    r, e, a = oracle.trapdoor_gen(moduli, n, base, sigma, d, master)
+    target = oracle.matrix_ntt(rand_matrix(oracle, 77, d, cols, moduli, n), moduli)
+    want = oracle.preimage(moduli, n, base, sigma, r, e, a, target, master)
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, sigma)
+    with seed_source(seeds):
+        td, A = sampler.trapdoor(p, d)
+        assert np.array_equal(td.r.to_rns(), r) and np.array_equal(td.e.to_rns(), e) and np.array_equal(A.to_rns(), a)
+        gt = gpu.GpuDCRTPolyMatrix.from_rns(p, target, True)
+        x = sampler.preimage(p, td, A, gt)
+    assert np.array_equal(x.ensure_eval().to_rns(), want)
+    assert A * x == gt
 
 
 @pytest.mark.parametrize("d,n,bits", [(1, 64, 24), (2, 32, 24), (1, 32, 51), (5, 16, 24)])
 @pytest.mark.parametrize("per_lane", ["", "3"])
-def test_p1_sampler_bit_exact(gpu, oracle, monkeypatch, per_lane, d, n, bits):
+def test_p1_sampler_bit_exact(gpu, oracle, hip_env, per_lane, d, n, bits):
     if per_lane:  # several elements per lane in the persistent-lane form (m <= 4)
-        monkeypatch.setenv("MXX_HIP_SAMPLER_PER_LANE", per_lane)
+        hip_env.set("MXX_HIP_SAMPLER_PER_LANE", per_lane)
     depth, base = 2, 12 if bits == 24 else 17
     p = make_params(gpu, oracle, n, depth, bits, base)
     moduli = p.moduli()

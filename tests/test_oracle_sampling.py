@@ -30,6 +30,48 @@ def test_rng_stream_is_keyed():
     assert len(set(int(x) for x in a)) == 24  # block counter advances
 
 
+def test_rng_streams_do_not_overlap():
+    """Block b of stream (s0, s1) must not be block 0 of stream (s0 + b, s1): the reference's layout
+    (counter = stream0, cuda/src/ChaCha.cu:138-149) has that overlap, and stream ids are consecutive
+    (poly + 1, column + 1, tower + 1), so neighbouring polynomials would share keystream."""
+    tag = 0x6F70656E66686532
+    seen = set()
+    for s0 in range(1, 6):
+        for s1 in range(1, 4):
+            words = O.rng_stream(SEED, s0, s1, 0, tag, 40)  # five 8-word blocks
+            for b in range(5):
+                blk = tuple(int(x) for x in words[8 * b : 8 * b + 8])
+                assert blk not in seen, (s0, s1, b)
+                seen.add(blk)
+    # stream words above 2^32 still select distinct streams (48 bits each are kept)
+    a = O.rng_stream(SEED, 1 << 33, 1, 0, tag, 8)
+    b = O.rng_stream(SEED, 1, 1 << 33, 0, tag, 8)
+    c = O.rng_stream(SEED, 0, 0, 0, tag, 8)
+    assert not np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(b, c)
+
+
+def test_detmath_against_libm():
+    """Box-Muller's log / cos(2 pi u) (mxx_amd/csrc/detmath.h, compiled into both sides) stay within
+    an ulp or two of libm: the samplers' normals are the same distribution, now reproducible."""
+    import ctypes as C
+    import math
+
+    lib = O.lib()
+    lib.orc_det_log.restype = C.c_double
+    lib.orc_det_log.argtypes = [C.c_double]
+    lib.orc_det_cos2pi.restype = C.c_double
+    lib.orc_det_cos2pi.argtypes = [C.c_double]
+    rng = np.random.default_rng(3)
+    us = np.concatenate([rng.random(20000), rng.random(2000) * 2.0 ** -rng.integers(1, 52, 2000) + 2.0**-53,
+                         [2.0**-53, 1 - 2.0**-53, 0.5, 0.25, 0.75, 0.125, 1 / 3]])
+    for u in us:
+        want = math.log(u)
+        assert abs(lib.orc_det_log(u) - want) <= 2 * abs(np.spacing(want)) + 1e-300
+        assert abs(lib.orc_det_cos2pi(u) - math.cos(2 * math.pi * u)) < 1e-15
+    assert lib.orc_det_cos2pi(0.25) == 0.0 or abs(lib.orc_det_cos2pi(0.25)) < 1e-16
+    assert lib.orc_det_cos2pi(0.5) == -1.0 and lib.orc_det_cos2pi(0.0) == 1.0
+
+
 @pytest.mark.parametrize("sigma,mean", [(4.578, 0.0), (1.0, 0.3), (137.5, -20.25), (0.8, 0.0)])
 def test_karney_moments(sigma, mean):
     x = O.karney_samples(SEED, 7, mean, sigma, 40000).astype(np.float64)
