@@ -324,6 +324,16 @@ void orc_pointwise(int op, uint64_t *out, const uint64_t *a, const uint64_t *b, 
         const uint64_t *av = a + (size_t)v * n;
         const uint64_t *bv = b + ((b_polys == 1 ? 0 : p) * L + l) * (size_t)n;
         uint64_t *ov = out + (size_t)v * n;
+        if (op == 2 && !(q >> 32)) {
+            /* word-sized modulus: Barrett with mu = floor(2^64 / q) instead of a 128-bit division */
+            const uint64_t mu = (uint64_t)((((u128)1) << 64) / q);
+            for (uint32_t i = 0; i < n; ++i) {
+                uint64_t prod = av[i] * bv[i];
+                uint64_t r = prod - (uint64_t)(((u128)prod * mu) >> 64) * q;
+                ov[i] = r >= q ? r - q : r;
+            }
+            continue;
+        }
         for (uint32_t i = 0; i < n; ++i) {
             uint64_t x = av[i], y = bv[i], r;
             if (op == 0) { r = x + y; if (r >= q) r -= q; }
@@ -361,8 +371,34 @@ void orc_matmul(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t rows
     }
 }
 
-/* Same product, cache-friendlier loop order (k outer, slots inner) with Barrett-free
- * 128-bit accumulators per slot: the CPU-baseline variant. */
+/* Same product, cache-friendlier loop order (k outer, slots inner): the CPU-baseline variant.
+ * Word-sized moduli (q < 2^32): products < 2^64 are summed lazily in 64-bit accumulators (as many
+ * as fit, one Barrett reduction per window; the multiply is the 32x32->64 form compilers vectorise);
+ * wider moduli: 128-bit accumulators. */
+static void matmul_lazy_u64(uint64_t *ov, const uint64_t *a, const uint64_t *b, size_t r, size_t c, size_t inner,
+                            size_t cols, uint32_t L, uint32_t l, uint32_t n, uint64_t q, uint64_t *acc) {
+    const u128 q2 = (u128)(q - 1) * (q - 1);
+    u128 win = ((((u128)1) << 64) - q) / q2;  /* (q-1) + win*(q-1)^2 < 2^64 */
+    const size_t window = win > (1u << 20) ? (1u << 20) : (size_t)win;
+    const uint64_t mu = (uint64_t)((((u128)1) << 64) / q);
+    for (uint32_t i = 0; i < n; ++i) acc[i] = 0;
+    size_t since = 0;
+    for (size_t k = 0; k < inner; ++k) {
+        const uint64_t *x = a + ((r * inner + k) * L + l) * (size_t)n;
+        const uint64_t *y = b + ((k * cols + c) * L + l) * (size_t)n;
+        for (uint32_t i = 0; i < n; ++i) acc[i] += (uint64_t)(uint32_t)x[i] * (uint32_t)y[i];
+        if (++since == window || k + 1 == inner) {
+            for (uint32_t i = 0; i < n; ++i) {
+                uint64_t v = acc[i];
+                uint64_t red = v - (uint64_t)(((u128)v * mu) >> 64) * q;
+                acc[i] = red >= q ? red - q : red;
+            }
+            since = 0;
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) ov[i] = acc[i];
+}
+
 void orc_matmul_fast(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t rows, size_t inner, size_t cols,
                      uint32_t L, uint32_t n, const uint64_t *moduli) {
     long total = (long)(rows * cols * L);
@@ -375,6 +411,10 @@ void orc_matmul_fast(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t
             size_t rc = (size_t)v / L;
             size_t r = rc / cols, c = rc % cols;
             uint64_t q = moduli[l];
+            if (!(q >> 32) && inner > 0) {
+                matmul_lazy_u64(out + (size_t)v * n, a, b, r, c, inner, cols, L, l, n, q, (uint64_t *)acc);
+                continue;
+            }
             /* how many q^2-bounded terms fit in 128 bits */
             for (uint32_t i = 0; i < n; ++i) acc[i] = 0;
             size_t since = 0;
@@ -483,4 +523,65 @@ void orc_ring_mul_batch(uint64_t *c, uint64_t *a, uint64_t *b, size_t polys, uin
     orc_matrix_ntt(b, polys, L, n, moduli, 0);
     orc_pointwise(2, c, a, b, polys, polys, L, n, moduli);
     orc_matrix_ntt(c, polys, L, n, moduli, 1);
+}
+
+/* ---- in-C timed baselines: inputs generated here (splitmix64), every repetition timed with
+ * CLOCK_MONOTONIC, no host-language work inside the timed region.  Thread count = orc_set_threads. ---- */
+#include <time.h>
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static inline uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+static uint64_t *bench_random(size_t polys, uint32_t L, uint32_t n, const uint64_t *moduli, uint64_t seed) {
+    uint64_t *m = malloc(sizeof(uint64_t) * polys * L * n);
+    if (!m) return NULL;
+    for (size_t p = 0; p < polys; ++p)
+        for (uint32_t l = 0; l < L; ++l) {
+            uint64_t s = seed ^ (p * 0x100000001b3ull + l);
+            uint64_t *v = m + (p * L + l) * (size_t)n;
+            for (uint32_t i = 0; i < n; ++i) v[i] = splitmix64(&s) % moduli[l];
+        }
+    return m;
+}
+
+/* (rows x inner) * (inner x cols) in EVAL form; sec[r] = seconds of repetition r (after one warm-up) */
+int orc_bench_matmul(size_t rows, size_t inner, size_t cols, uint32_t L, uint32_t n, const uint64_t *moduli, int reps,
+                     double *sec) {
+    uint64_t *a = bench_random(rows * inner, L, n, moduli, 0x6d7878 ^ 4), *b = bench_random(inner * cols, L, n, moduli, 0x6d7878 ^ 5);
+    uint64_t *c = malloc(sizeof(uint64_t) * rows * cols * L * n);
+    if (!a || !b || !c) { free(a); free(b); free(c); return 1; }
+    orc_matmul_fast(c, a, b, rows, inner, cols, L, n, moduli);
+    for (int r = 0; r < reps; ++r) {
+        double t0 = now_s();
+        orc_matmul_fast(c, a, b, rows, inner, cols, L, n, moduli);
+        sec[r] = now_s() - t0;
+    }
+    free(a); free(b); free(c);
+    return 0;
+}
+
+/* workload M1 on `polys` polynomials: x <- INTT(NTT(x) o w); sec[3*r + {0,1,2}] = forward NTT,
+ * pointwise product, inverse NTT of repetition r */
+int orc_bench_ring_mul(size_t polys, uint32_t L, uint32_t n, const uint64_t *moduli, int reps, double *sec) {
+    uint64_t *x = bench_random(polys, L, n, moduli, 0x6d7878 ^ 2), *w = bench_random(1, L, n, moduli, 0x6d7878 ^ 3);
+    if (!x || !w) { free(x); free(w); return 1; }
+    for (int r = -1; r < reps; ++r) {
+        double t0 = now_s();
+        orc_matrix_ntt(x, polys, L, n, moduli, 0);
+        double t1 = now_s();
+        orc_pointwise(2, x, x, w, polys, 1, L, n, moduli);
+        double t2 = now_s();
+        orc_matrix_ntt(x, polys, L, n, moduli, 1);
+        double t3 = now_s();
+        if (r >= 0) { sec[3 * r] = t1 - t0; sec[3 * r + 1] = t2 - t1; sec[3 * r + 2] = t3 - t2; }
+    }
+    free(x); free(w);
+    return 0;
 }
