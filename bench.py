@@ -1,369 +1,690 @@
 #!/usr/bin/env python3
-"""bench.py — ring-ops/s of the DCRT hot path on MI355X, next to the roofline and the CPU path.
+"""bench.py — DCRT poly-matrix mul ring-ops/s + trapdoor preimages/s on MI355X (BASELINE.json's metric),
+next to the kernel's roofline and the CPU path timed on the same box.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload m1|m2a|m2b|m3a|m3b]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload default|m1|m2a|m2b|m3a|m3b|m4]
+                    [--scaling strong|weak] [--repeats R] [--no-cpu-baseline]
 
-Default workload = BASELINE.json configs[1] ("M1"): n=2^14, 4 RNS limbs
-(24-bit), batch of 1024 polynomials resident in HBM.  One step = one pass of the hot path
-over the batch: x <- INTT( NTT(x) o w ) for all 1024 polynomials, i.e. 1024 ring
-multiplications (ring-ops) by a resident EVAL-form ring element w, through the C ABI
-(gpu_matrix_ntt_all, gpu_matrix_mul_scalar, gpu_matrix_intt_all).
-Other workloads: m2a = the reference's benches/bench_matrix_mul_gpu.rs shape
-(n=2^14, L=15, (1x30)*(30x120) = 3600 ring-ops/step); m2b = 64x64 * 64x64, L=8;
-m3a = benches/bench_preimage_gpu.rs (n=2^14, L=10, sigma=4.578, d=1, 50 target columns;
-unit preimages/s); m3b = BASELINE.json configs[3]: the same with L=8 - with N>1 every rank samples the preimages
-of its own 50 target columns (the partition of preimage_batched_sharded) and the preimage blocks are all-gathered
-over RCCL/xGMI, the one exchange step of that configuration.
+Default (what the driver runs): the two shapes the metric is quoted on, in ONE JSON line
+  * main block  = M2A, the reference's benches/bench_matrix_mul_gpu.rs:20-34 shape: n=2^14, L=15 (24-bit),
+    (1x30)*(30x120) in EVAL form = 3600 ring-ops per step, metric dcrt_ring_ops_per_s
+    (1 ring-op = one R_q multiply-accumulate = n*L modular MACs);
+  * "preimage"  = M3A, benches/bench_preimage_gpu.rs:7-56: n=2^14, L=10, base 2^12, sigma=4.578, d=1,
+    50 uniform target columns per call, unit preimages/s (target columns per second);
+  * "kernels"   = the NTT / INTT / pointwise mod-mul kernels of BASELINE configs[1] (M1: n=2^14, L=4,
+    1024 polynomials) with their achieved HBM GB/s from hipEvents.
+Always synchronises before stopping the clock (the reference's mat-mul bench does not).
 
-N>1: one process per GPU (torch.distributed / RCCL only for the barrier and the
-max-over-ranks clock); the path shards by independent polynomials / target columns with
-no data-path collective, so every rank runs the same per-GPU batch ("scaling": "weak").
+Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + device-synchronise brackets, MAX over
+ranks (`value`, `ms_per_step`); after that R further repetitions of the K steps give `repeats` (median / min)
+- BASELINE.md section 4 asks for both.  `roofline.kernel` is the kernel with the largest hipEvent total.
+
+N>1: `python bench.py --gpus N` spawns its N ranks itself (before any GPU call; the driver's torchrun launch is
+detected through WORLD_SIZE and used as is).  One process per GPU; `--scaling strong` (default) splits the
+SAME problem: B/C column blocks (120 -> 15 per GPU at N=8) and target columns (50 -> 7,7,6,...) by
+mxx_amd.parallel.shard_range, every step ending in one RCCL all-gather of the blocks over xGMI
+(SURVEY.md 8e); `--scaling weak` runs the full shape on every rank with no collective.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-BASIS_24 = None
-
-
-def moduli_24(gen, n, depth):
-    return gen(n, depth, 24)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+N_RING = 16384
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="m1", choices=["m1", "m2a", "m2b", "m3a", "m3b"])
+    ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m3a", "m3b", "m4"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K steps for median / min")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per block")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo only rehearses the launcher / rendezvous on a GPU-less box (with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous + one all-reduce, no GPU work")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: --gpus N without torchrun
+# ---------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args) -> int:
+    """Spawn one fresh child per rank (this process never touches the GPU), relay rank 0's output,
+    fail if any rank fails."""
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        out = None if rank == 0 else subprocess.DEVNULL  # rank 0 prints the JSON line; stderr stays visible
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        for p in procs:  # only the children started here, by PID
+            if p.poll() is None:
+                p.terminate()
+    return rc
 
 
 class Dist:
-    """torch.distributed only when N>1 (importing torch costs minutes on a fresh box)."""
+    """torch.distributed when the job has more than one rank (RCCL = backend "nccl" on ROCm)."""
 
-    def __init__(self, n_gpus: int):
-        self.world = n_gpus
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.torch = None
-        if n_gpus > 1 or os.environ.get("MXX_BENCH_FORCE_DIST") == "1":  # the env rehearses the N>1 path on one GPU
+        self.torch = self.dist = None
+        self.backend = args.dist_backend
+        if self.world > 1 or os.environ.get("MXX_BENCH_FORCE_DIST") == "1":  # the env rehearses the N>1 path on one GPU
+            # torch must be imported BEFORE libgpupoly is loaded: the wheel bundles its own libamdhip64 and
+            # a process must hold exactly one HIP runtime (libgpupoly then binds to the copy torch mapped)
             import torch
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend="gloo")
             self.torch, self.dist = torch, dist
+            self.world = dist.get_world_size()
+            self.rank = dist.get_rank()
 
-    def barrier_sync(self, mx):
-        mx.gpu_device_sync()
-        if self.torch is not None:
-            self.torch.cuda.synchronize()
+    @property
+    def active(self):
+        return self.torch is not None
+
+    def device(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier_sync(self, sync_engine):
+        sync_engine()
+        if self.active:
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
             self.dist.barrier()
-            self.torch.cuda.synchronize()
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
 
     def max_over_ranks(self, value: float) -> float:
-        if self.torch is None:
+        if not self.active:
             return value
-        t = self.torch.tensor([value], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def finish(self):
-        if self.torch is not None:
+        if self.active:
             self.dist.barrier()
             self.dist.destroy_process_group()
 
 
-def upload_random(mx, params, rows, cols, seed, eval_format, chunk_polys=256):
-    """Fill a device matrix with i.i.d. uniform residues (splitmix64), chunked uploads."""
-    from mxx_amd import _ffi
+# ---------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------
+def fixed_seed(mx, tag: int):
+    return mx.GpuRngSeed.from_bytes(bytes([(tag * 37 + i * 11 + 5) & 0xFF for i in range(32)]))
 
-    n, moduli = params.ring_dimension(), params.moduli()
-    L = len(moduli)
-    out = mx.GpuDCRTPolyMatrix(params, rows, cols, L - 1, eval_format)
-    q = np.asarray(moduli, dtype=np.uint64).reshape(1, L, 1)
-    total = rows * cols
-    rng = np.random.Generator(np.random.SFC64(seed))
-    # upload row blocks through copy_block of a staging matrix to bound host memory
-    flat = mx.GpuDCRTPolyMatrix(params, 1, min(chunk_polys, total), L - 1, eval_format)
-    done = 0
-    while done < total:
-        cnt = min(chunk_polys, total - done)
-        host = rng.integers(0, 1 << 63, size=(cnt, L, n), dtype=np.uint64) % q
-        if cnt != flat.ncol:
-            flat = mx.GpuDCRTPolyMatrix(params, 1, cnt, L - 1, eval_format)
-        flat.load_rns(host.reshape(1, cnt, L, n), eval_format)
-        # polys are row-major contiguous: copy as a 1 x cnt run when aligned to rows, else entry-wise
-        p = done
-        off = 0
-        while off < cnt:
-            r, c = divmod(p, cols)
-            run = min(cols - c, cnt - off)
-            out.copy_block_from(flat, r, c, 0, off, 1, run)
-            out.is_ntt = eval_format
-            p += run
-            off += run
-        done += cnt
+
+def uniform_matrix(mx, params, rows, cols, tag, total_cols=None, col_start=0):
+    """Synthetic i.i.d. uniform residues, generated on the device (EVAL form), deterministic in `tag`;
+    a column window of the same logical matrix when total_cols is given."""
+    code = mx.DistType.FinRingDist().as_ffi()
+    if total_cols is None:
+        return mx.GpuDCRTPolyMatrix.sample_distribution(params, rows, cols, code, 0.0, fixed_seed(mx, tag))
+    return mx.GpuDCRTPolyMatrix.sample_distribution_columns(params, rows, total_cols, col_start, cols, code, 0.0,
+                                                             fixed_seed(mx, tag))
+
+
+class Workload:
+    """A step = one pass of the hot path over one batch; marks bracket its dominant kernel(s)."""
+
+    metric = "dcrt_ring_ops_per_s"
+    unit = "ring-ops/s"
+    name = ""
+    depth = 0
+    kernels = ()  # ((label, algorithmic bytes per launch), ...) in the order step() marks them
+
+    def __init__(self, mx, d: Dist, args, device: int):
+        self.mx, self.d, self.args = mx, d, args
+        # MXX_BENCH_FORCE_DIST=1 rehearses the sharded path (partition + RCCL gather) with a world of one rank
+        self.strong = args.scaling == "strong" and (d.world > 1 or d.active)
+        self.params = mx.GpuDCRTPolyParams(N_RING if self.name != "m4" else 256, self.moduli(mx), self.base_bits(),
+                                           gpu_ids=[device])
+        self.ctx = self.params.ctx()
+        self.word = self.ctx.word_bytes()
+        self.device = device
+        self.nmarks = len(self.kernels) + 1
+
+    def moduli(self, mx):
+        return mx.gen_crt_basis(N_RING, self.depth, 24)
+
+    def base_bits(self):
+        return 12
+
+    def mark(self, step, j):
+        self.ctx.timer_mark(step * self.nmarks + j)
+
+    def kernel_ms(self, steps):
+        """mean hipEvent duration of every marked kernel over the timed steps"""
+        out = []
+        for j in range(len(self.kernels)):
+            out.append(statistics.fmean(self.ctx.timer_elapsed(s * self.nmarks + j, s * self.nmarks + j + 1) for s in range(steps)))
+        return out
+
+    def check(self):
+        pass
+
+
+class M1(Workload):
+    name, depth = "m1", 4
+
+    def setup(self):
+        mx, p = self.mx, self.params
+        self.batch = 1024
+        self.x = uniform_matrix(mx, p, self.batch, 1, 2)
+        self.x.intt_all_in_place()
+        self.w = uniform_matrix(mx, p, 1, 1, 3)
+        self.units = self.batch  # weak only: batches are independent polynomials
+        vec = 2.0 * N_RING * self.word * self.batch * self.depth  # 2*n*w per (poly, limb)
+        self.kernels = (("ntt14::fwd_kernel<u32> (forward negacyclic NTT, 2^14 points)", vec),
+                        ("elementwise_kernel<u32,mul,bcast> (pointwise mod-mul by a resident ring element)", vec),
+                        ("ntt14::inv_kernel<u32,signed> (inverse negacyclic NTT)", vec))
+        self.nmarks = 4
+        self.desc = (f"M1 (BASELINE configs[1]): n=2^14, L=4 (24-bit), batch {self.batch} polys; "
+                     f"step = x<-INTT(NTT(x) o w) = {self.batch} ring mults")
+        self.sharding = "independent polynomial batches per rank, no collective"
+
+    def step(self, i, mark):
+        from mxx_amd import _ffi
+
+        lib = _ffi.lib()
+        if mark:
+            self.mark(i, 0)
+        _ffi.check_status(lib.gpu_matrix_ntt_all(self.x.raw), "gpu_matrix_ntt_all")
+        if mark:
+            self.mark(i, 1)
+        _ffi.check_status(lib.gpu_matrix_mul_scalar(self.x.raw, self.x.raw, self.w.raw), "gpu_matrix_mul_scalar")
+        if mark:
+            self.mark(i, 2)
+        _ffi.check_status(lib.gpu_matrix_intt_all(self.x.raw), "gpu_matrix_intt_all")
+        if mark:
+            self.mark(i, 3)
+
+
+class MatMul(Workload):
+    def setup(self):
+        mx, p, d = self.mx, self.params, self.d
+        r, k, c = self.shape
+        L = self.depth
+        self.a = uniform_matrix(mx, p, r, k, 4)
+        if self.strong:
+            from mxx_amd.parallel import ColumnAllGather, shard_range
+
+            sr = shard_range(c, d.world, d.rank)
+            self.c_local = len(sr)
+            self.b = uniform_matrix(mx, p, k, self.c_local, 5, total_cols=c, col_start=sr.start)
+            self.gather = ColumnAllGather(p, r, c, L - 1, d.torch, d.dist, self.device)
+            self.sharding = (f"strong: B/C column blocks by shard_range ({c} -> {self.c_local} on this rank), "
+                             "A replicated, one RCCL all-gather of C's blocks per step")
+            self.units_total = r * k * c  # the whole job's ring-ops per step
+        else:
+            self.c_local = c
+            self.b = uniform_matrix(mx, p, k, c, 5)
+            self.gather = None
+            self.sharding = "weak: every rank multiplies the full shape, no collective" if d.world > 1 else "single GPU"
+            self.units_total = r * k * c * d.world
+        self.out = mx.GpuDCRTPolyMatrix(p, r, max(self.c_local, 1), L - 1, True)
+        self.units = self.units_total
+        algo = float(r * k + k * self.c_local + r * self.c_local) * N_RING * L * self.word  # SURVEY 8d, this rank's launch
+        self.kernels = ((self.kernel_label, algo),)
+        self.nmarks = 2
+        self.desc = (f"{self.name.upper()}: n=2^14, L={L} (24-bit), ({r}x{k})*({k}x{c}) in EVAL form; "
+                     "1 ring-op = one R_q multiply-accumulate")
+
+    def step(self, i, mark):
+        from mxx_amd import _ffi
+
+        if mark:
+            self.mark(i, 0)
+        if self.c_local:
+            _ffi.check_status(_ffi.lib().gpu_matrix_mul(self.out.raw, self.a.raw, self.b.raw), "gpu_matrix_mul")
+        if mark:
+            self.mark(i, 1)
+        if self.gather is not None:
+            self.full = self.gather.gather(self.out if self.c_local else self.out.slice_columns(0, 0))
+
+    def check(self):
+        """size-independent property on the timed operands: (A*B) == columns of A*[B] recomputed entry-wise
+        for one column through the ring (a second, different kernel path is used by the 1-column product)"""
+        col = self.b.slice_columns(0, 1) if self.c_local else None
+        if col is not None:
+            one = self.a * col
+            assert one == self.out.slice_columns(0, 1), "product column differs between kernel paths"
+
+
+class M2A(MatMul):
+    name, depth, shape = "m2a", 15, (1, 30, 120)
+    kernel_label = "matmul_kernel<u32,1,8,4> (R_q matrix product, skinny: B streamed once)"
+
+
+class M2B(MatMul):
+    name, depth, shape = "m2b", 8, (64, 64, 64)
+    kernel_label = "fat R_q matrix product (mmfma / mmdma kernel, see config.matmul_path)"
+
+
+class Preimage(Workload):
+    metric, unit = "trapdoor_preimages_per_s", "preimages/s"
+    sigma, dsize, cols = 4.578, 1, 50
+
+    def setup(self):
+        mx, p, d = self.mx, self.params, self.d
+        self.sampler = mx.GpuDCRTPolyTrapdoorSampler(p, self.sigma)
+        from mxx_amd.sampler import seed_source
+
+        # fixed seeds for the trapdoor so that every rank holds the SAME trapdoor / public matrix (replicated
+        # read-only operands); the per-call sampler seeds stay OS-random as in the reference
+        with seed_source(bytes([(7 * j + i) & 0xFF for i in range(32)]) for j in range(3)):
+            self.td, self.pub = self.sampler.trapdoor(p, self.dsize)
+        k = p.modulus_digits()
+        if self.strong:
+            from mxx_amd.parallel import ColumnAllGather, shard_range
+
+            sr = shard_range(self.cols, d.world, d.rank)
+            self.c_local = len(sr)
+            self.target = uniform_matrix(mx, p, self.dsize, self.c_local, 9, total_cols=self.cols, col_start=sr.start)
+            self.gather = ColumnAllGather(p, (k + 2) * self.dsize, self.cols, self.depth - 1, d.torch, d.dist, self.device)
+            self.sharding = (f"strong: {self.cols} target columns by shard_range ({self.c_local} on this rank), trapdoor "
+                             "replicated, one RCCL all-gather of the preimage blocks per call")
+            self.units = self.cols
+        else:
+            self.c_local = self.cols
+            self.target = uniform_matrix(mx, p, self.dsize, self.cols, 9)
+            self.gather = None
+            self.sharding = "weak: every rank samples all 50 columns, no collective" if d.world > 1 else "single GPU"
+            self.units = self.cols * d.world
+        self.kernels = (("preimage call (all kernels; per-kernel split in profiles/)", None),)
+        self.nmarks = 2
+        self.desc = (f"{self.name.upper()}: bench_preimage shape n=2^14, L={self.depth}, base 2^12, sigma={self.sigma}, "
+                     f"d=1, {self.cols} target columns per call")
+        self.x = None
+
+    def step(self, i, mark):
+        if mark:
+            self.mark(i, 0)
+        if self.c_local:
+            self.x = self.sampler.preimage(self.params, self.td, self.pub, self.target)
+        if mark:
+            self.mark(i, 1)
+        if self.gather is not None:
+            self.full = self.gather.gather(self.x)
+
+    def check(self):
+        if self.c_local:
+            assert self.pub * self.x == self.target, "A*x != u"
+        if self.gather is not None and self.c_local:
+            from mxx_amd.parallel import shard_range
+
+            sr = shard_range(self.cols, self.d.world, self.d.rank)
+            assert self.full.slice_columns(sr.start, sr.stop) == self.x, "gathered preimage block differs"
+
+
+class M3A(Preimage):
+    name, depth = "m3a", 10
+
+
+class M3B(Preimage):
+    name, depth = "m3b", 8
+
+
+class M4(Workload):
+    """BASELINE configs[4] flavour: the parameter family of tests/test_gpu_ggh15_modp_chain.rs:36-42 (n=256, 51-bit
+    limbs, base 2^17, depth <= 12) as the chain those schemes run per level: preimage of a 2d-column target,
+    encoding * key, mul_decompose - launch-bound (u64 words, ~100 small launches per step)."""
+
+    name, depth = "m4", 12
+    metric, unit = "trapdoor_preimages_per_s", "preimages/s"
+
+    def moduli(self, mx):
+        return mx.gen_crt_basis(256, self.depth, 51)
+
+    def base_bits(self):
+        return 17
+
+    def setup(self):
+        mx, p = self.mx, self.params
+        d = 2
+        self.dd = d
+        self.sampler = mx.GpuDCRTPolyTrapdoorSampler(p, 4.578)
+        self.td0, self.a0 = self.sampler.trapdoor(p, d)
+        _, a1 = self.sampler.trapdoor(p, d)
+        self.target = a1.slice(0, d, 0, 2 * d)
+        k = p.modulus_digits()
+        us = mx.GpuDCRTPolyUniformSampler()
+        self.c0 = us.sample_uniform(p, 1, self.a0.col_size(), mx.DistType.FinRingDist())
+        self.bmat = us.sample_uniform(p, d, d * k, mx.DistType.FinRingDist())
+        self.mmat = us.sample_uniform(p, d, 3, mx.DistType.FinRingDist())
+        self.units = 2 * d * self.d.world  # target columns per step
+        self.kernels = (("chain step (launch-bound; launches per step in config)", None),)
+        self.nmarks = 2
+        self.desc = (f"M4 (BASELINE configs[4] parameters): n=256, L={self.depth} (51-bit, u64 words), base 2^17, d={d}; step = "
+                     f"preimage of {2 * d} columns + (1x{self.a0.col_size()})*K + mul_decompose({d}x{d * k}, {d}x3)")
+        self.sharding = "independent chains per rank, no collective"
+
+    def step(self, i, mark):
+        if mark:
+            self.mark(i, 0)
+        self.k = self.sampler.preimage(self.params, self.td0, self.a0, self.target)
+        self.c1 = self.c0 * self.k
+        self.md = self.bmat.mul_decompose(self.mmat)
+        if mark:
+            self.mark(i, 1)
+
+    def check(self):
+        assert self.a0 * self.k == self.target, "A*x != u"
+        assert self.mx.GpuDCRTPolyMatrix.gadget_matrix(self.params, self.dd) * self.mmat.decompose() == self.mmat
+
+
+WORKLOADS = {"m1": M1, "m2a": M2A, "m2b": M2B, "m3a": M3A, "m3b": M3B, "m4": M4}
+
+
+# ---------------------------------------------------------------------------------------------------
+# measurement
+# ---------------------------------------------------------------------------------------------------
+def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
+    """The contract's timed region (K steps, barrier + synchronise on both sides, MAX over ranks), then
+    `repeats` more repetitions of the same K steps for median / min."""
+    mx = wl.mx
+    for i in range(warmup):
+        wl.step(i, False)
+    d.barrier_sync(mx.gpu_device_sync)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wl.step(i, True)
+    d.barrier_sync(mx.gpu_device_sync)
+    elapsed = d.max_over_ranks(time.perf_counter() - t0)
+    kernel_ms = wl.kernel_ms(steps)
+    reps = []
+    for _ in range(repeats):
+        d.barrier_sync(mx.gpu_device_sync)
+        t1 = time.perf_counter()
+        for i in range(steps):
+            wl.step(i, False)
+        d.barrier_sync(mx.gpu_device_sync)
+        reps.append(d.max_over_ranks(time.perf_counter() - t1) * 1e3 / steps)
+    wl.check()
+    all_ms = [elapsed * 1e3 / steps] + reps
+    return {
+        "elapsed_s": elapsed,
+        "ms_per_step": elapsed * 1e3 / steps,
+        "value": wl.units * steps / elapsed,
+        "kernel_ms": kernel_ms,
+        "repeats": {"count": len(all_ms), "steps_each": steps, "median_ms_per_step": statistics.median(all_ms),
+                    "min_ms_per_step": min(all_ms), "max_ms_per_step": max(all_ms),
+                    "value_at_median": wl.units / (statistics.median(all_ms) * 1e-3)},
+    }
+
+
+def roofline_of(wl: Workload, kernel_ms):
+    """The marked kernel with the largest hipEvent time that has an algorithmic byte count."""
+    cands = [(ms, label, algo) for (label, algo), ms in zip(wl.kernels, kernel_ms) if algo]
+    if not cands:
+        label, ms = wl.kernels[0][0], kernel_ms[0]
+        return {"bound": "hbm", "kernel": label, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "kernel_ms": round(ms, 4)}
+    ms, label, algo = max(cands)
+    achieved = algo / (ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{wl.name}.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": algo,
+            "kernel_ms": round(ms, 5)}
+
+
+def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
+    return {
+        "metric": wl.metric,
+        "value": res["value"],
+        "unit": wl.unit,
+        "n_gpus": d.world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": args.scaling if d.world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "u32" if wl.word == 4 else "u64",
+        "data": "synthetic",
+        "config": {"workload": wl.desc, "ring_dim": wl.params.ring_dimension(), "limbs": wl.depth,
+                   "limb_bits": 24 if wl.word == 4 else 51, "units_per_step": wl.units, "sharding": wl.sharding},
+        "repeats": res["repeats"],
+        "roofline": roofline_of(wl, res["kernel_ms"]),
+    }
+
+
+def kernels_block(m1: Workload, res):
+    out = {"workload": m1.desc}
+    for (label, algo), ms in zip(m1.kernels, res["kernel_ms"]):
+        key = "ntt_forward" if "fwd" in label else ("ntt_inverse" if "inv_kernel" in label else "mod_mul")
+        out[key] = {"kernel": label, "us": round(ms * 1e3, 2), "algorithmic_bytes": algo,
+                    "achieved_GBps": round(algo / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    out["step_ms"] = res["ms_per_step"]
+    out["ring_mults_per_s"] = res["value"]
     return out
 
 
 def main():
     args = parse_args()
-    # torch (N>1 only) must be imported BEFORE libgpupoly is loaded: the wheel bundles its own
-    # libamdhip64.so.7, and a process must hold exactly one HIP runtime; loaded in this order
-    # libgpupoly binds to the copy torch already mapped (same soname)
-    d = Dist(args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # nothing GPU-related has been imported or called in this process
+
+    d = Dist(args)
+    if args.dry_run:
+        ok = 1.0
+        if d.active:
+            t = d.torch.ones(1, dtype=d.torch.float64, device=d.device())
+            d.dist.all_reduce(t)
+            ok = float(t.item())
+        if d.rank == 0:
+            print(json.dumps({"dry_run": True, "world": d.world, "all_reduce": ok, "backend": d.backend if d.active else None}), flush=True)
+        d.finish()
+        return
+    if d.active and d.world != args.gpus and d.rank == 0:
+        print(f"bench.py: note: --gpus {args.gpus} but the job has {d.world} ranks; reporting the job's world size", file=sys.stderr)
+
     import mxx_amd as mx
-    from mxx_amd import _ffi
 
     if mx.detected_gpu_device_count() == 0:
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    device = d.local_rank if d.torch is not None else 0
-    n = 16384
-    wl = args.workload
-    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m3a": 10, "m3b": 8}[wl]
-    moduli = mx.gen_crt_basis(n, depth, 24)
-    params = mx.GpuDCRTPolyParams(n, moduli, 12, gpu_ids=[device])
-    ctx = params.ctx()
-    word = ctx.word_bytes()
-    L = depth
+    device = d.local_rank if d.active else 0
     steps, warmup = args.steps, args.warmup
-    roof = None
-    extra = {}
 
-    if wl == "m1":
-        batch = 1024
-        x = upload_random(mx, params, batch, 1, 0x6D7878 ^ 2, False)
-        w = upload_random(mx, params, 1, 1, 0x6D7878 ^ 3, True)
-        lib = _ffi.lib()
+    def run(name, steps_, warmup_, repeats_):
+        wl = WORKLOADS[name](mx, d, args, device)
+        wl.setup()
+        res = run_block(wl, d, steps_, warmup_, repeats_)
+        return wl, res
 
-        def step(i, mark):
-            if mark:
-                ctx.timer_mark(2 * i)
-            _ffi.check_status(lib.gpu_matrix_ntt_all(x.raw), "gpu_matrix_ntt_all")
-            if mark:
-                ctx.timer_mark(2 * i + 1)
-            _ffi.check_status(lib.gpu_matrix_mul_scalar(x.raw, x.raw, w.raw), "gpu_matrix_mul_scalar")
-            _ffi.check_status(lib.gpu_matrix_intt_all(x.raw), "gpu_matrix_intt_all")
-
-        units_per_step = batch
-        metric, unit = "dcrt_ring_ops_per_s", "ring-ops/s"
-        kernel_name = "ntt14::fwd_kernel<uint32_t> (forward negacyclic NTT, 2^14 points)"
-        algo_bytes = 2.0 * n * word * batch * L  # 2*n*w per (poly, limb)
-        workload_desc = f"M1: n=2^14, L=4 (24-bit), batch {batch} polys; step = x<-INTT(NTT(x) o w) = {batch} ring mults"
-    elif wl in ("m2a", "m2b"):
-        r, k, c = (1, 30, 120) if wl == "m2a" else (64, 64, 64)
-        a = upload_random(mx, params, r, k, 0x6D7878 ^ 4, True)
-        b = upload_random(mx, params, k, c, 0x6D7878 ^ 5, True)
-        out = mx.GpuDCRTPolyMatrix(params, r, c, L - 1, True)
-        lib = _ffi.lib()
-
-        gather = None
-        if d.torch is not None:
-            # the one real exchange step of the sharded product: every rank owns a block of
-            # `c` output columns and all-gathers the blocks over xGMI (RCCL), zero-copy from
-            # the engine's HBM allocation
-            from mxx_amd.parallel import DeviceBuffer
-
-            src_t = DeviceBuffer(out).tensor(device)
-            full_t = d.torch.empty(d.dist.get_world_size() * src_t.numel(), dtype=src_t.dtype, device=src_t.device)
-            gather = (src_t, full_t)
-
-        def step(i, mark):
-            if mark:
-                ctx.timer_mark(2 * i)
-            _ffi.check_status(lib.gpu_matrix_mul(out.raw, a.raw, b.raw), "gpu_matrix_mul")
-            if mark:
-                ctx.timer_mark(2 * i + 1)
-            if gather is not None:
-                mx.gpu_device_sync()  # engine stream -> torch stream hand-off
-                d.dist.all_gather_into_tensor(gather[1], gather[0])
-
-        units_per_step = r * k * c
-        metric, unit = "dcrt_ring_ops_per_s", "ring-ops/s"
-        kernel_name = "matmul_kernel<uint32_t,...> / mmdma::kernel_u32 (R_q matrix product, EVAL)"
-        algo_bytes = float(r * k + k * c + r * c) * n * L * word
-        workload_desc = f"{wl.upper()}: n=2^14, L={L} (24-bit), ({r}x{k})*({k}x{c}); 1 ring-op = one R_q multiply-accumulate"
-    else:  # m3a / m3b
-        sigma, dsize, cols = 4.578, 1, 50
-        sampler = mx.GpuDCRTPolyTrapdoorSampler(params, sigma)
-        td, pub = sampler.trapdoor(params, dsize)
-        target = mx.GpuDCRTPolyUniformSampler().sample_uniform(params, dsize, cols, mx.DistType.FinRingDist())
-        keep = {}
-        gather_full = None
-        if d.torch is not None and wl == "m3b":
-            from mxx_amd.parallel import DeviceBuffer
-
-            words = (params.modulus_digits() + 2) * dsize * cols * L * n  # one rank's preimage block
-            gather_full = d.torch.empty(d.dist.get_world_size() * words * word, dtype=d.torch.uint8, device=device)
-
-        def step(i, mark):
-            if mark:
-                ctx.timer_mark(2 * i)
-            keep["x"] = sampler.preimage(params, td, pub, target)
-            if mark:
-                ctx.timer_mark(2 * i + 1)
-            if gather_full is not None:
-                mx.gpu_device_sync()  # engine stream -> torch stream hand-off
-                d.dist.all_gather_into_tensor(gather_full, DeviceBuffer(keep["x"]).tensor(device))
-
-        units_per_step = cols
-        metric, unit = "trapdoor_preimages_per_s", "preimages/s"
-        kernel_name = "preimage call (all kernels)"
-        algo_bytes = None
-        workload_desc = (f"{wl.upper()}: bench_preimage shape n=2^14, L={L}, base 2^12, sigma={sigma}, d=1, {cols} target columns"
-                         + (" per rank, preimage blocks all-gathered (RCCL)" if gather_full is not None else ""))
-
-    for i in range(warmup):
-        step(i, False)
-    d.barrier_sync(mx)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i, True)
-    d.barrier_sync(mx)
-    elapsed = time.perf_counter() - t0
-    elapsed = d.max_over_ranks(elapsed)
-
-    if wl in ("m3a", "m3b"):
-        x = keep["x"]
-        assert pub * x == target, "A*x != u"
-
-    result = None
+    if args.workload == "default":
+        wl, res = run("m2a", steps, warmup, args.repeats)
+        line = block_json(wl, res, d, args, steps, warmup)
+        del wl
+        pre_wl, pre_res = run("m3a", steps, warmup, min(args.repeats, 3))
+        pre = block_json(pre_wl, pre_res, d, args, steps, warmup)
+        for key in ("n_gpus", "higher_is_better", "vs_baseline", "data", "scaling"):
+            pre.pop(key, None)
+        pre.pop("roofline", None)
+        pre["call_ms_hipevents"] = round(pre_res["kernel_ms"][0], 4)
+        line["preimage"] = pre
+        del pre_wl
+        m1, m1_res = run("m1", steps, warmup, 0)
+        line["kernels"] = kernels_block(m1, m1_res)
+        del m1
+        if d.rank == 0 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline("m2a", args.cpu_seconds)
+            line["preimage"]["cpu_baseline"] = cpu_baseline("m3a", args.cpu_seconds)
+            line["kernels"]["cpu_baseline"] = cpu_baseline("m1", args.cpu_seconds / 2)
+    else:
+        wl, res = run(args.workload, steps, warmup, args.repeats)
+        line = block_json(wl, res, d, args, steps, warmup)
+        if args.workload == "m1":
+            line["kernels"] = kernels_block(wl, res)
+        if d.rank == 0 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
     if d.rank == 0:
-        ms_per_step = elapsed * 1e3 / steps
-        value = units_per_step * steps * args.gpus / elapsed
-        kernel_ms = float(np.mean([ctx.timer_elapsed(2 * i, 2 * i + 1) for i in range(steps)]))
-        if algo_bytes is not None:
-            achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{wl}.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {
-                "bound": "hbm",
-                "kernel": kernel_name,
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "kernel_ms": round(kernel_ms, 5),
-            }
-        else:
-            roof = {"bound": "hbm", "kernel": kernel_name, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": None, "traffic": None, "kernel_ms": round(kernel_ms, 4)}
-        cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(wl, n, moduli, args.cpu_seconds)
-        result = {
-            "metric": metric,
-            "value": value,
-            "unit": unit,
-            "n_gpus": args.gpus,
-            "steps": steps,
-            "warmup": warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": workload_desc, "ring_dim": n, "limbs": L, "limb_bits": 24,
-                       "units_per_step_per_gpu": units_per_step,
-                       "sharding": ("column blocks per rank + RCCL all-gather of the result" if (wl in ("m2a", "m2b", "m3b") and args.gpus > 1)
-                                    else "independent polys / target columns per rank, no collective")},
-            "roofline": roof,
-            "cpu_baseline": cpu,
-        }
-        print(json.dumps(result), flush=True)
+        line.setdefault("cpu_baseline", None)
+        print(json.dumps(line), flush=True)
     d.finish()
 
 
-def cpu_baseline(wl, n, moduli, budget_s):
-    """The CPU restatement (oracle/, kind 'port') on this box's host cores, bounded sample."""
-    from oracle import oracle as O
-
-    # the box's CPU share, not the host's thread count (a 1-GPU box gets a slice of the host)
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1 semantics): the CPU restatement under oracle/, built -march=native on THIS box,
+# timed inside C (CLOCK_MONOTONIC around the kernels, inputs generated in C), median of >= 5 repetitions after a
+# warm-up, on all host cores of the box's share and on 1 core
+# ---------------------------------------------------------------------------------------------------
+def host_cores() -> int:
     cores = len(os.sched_getaffinity(0))
-    try:
+    try:  # the box's CPU share, not the host's thread count
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except Exception:
         pass
-    O.lib().orc_set_threads(cores)
-    L = len(moduli)
-    if wl == "m1":
-        polys = 128
-        x = O.random_matrix(1, polys, 1, moduli, n)
-        w = O.matrix_ntt(O.random_matrix(2, 1, 1, moduli, n), moduli)
+    return cores
 
-        def run():
-            y = O.matrix_ntt(x, moduli)
-            y = O.pointwise("mul", y, w, moduli)
-            return O.matrix_ntt(y, moduli, inverse=True)
 
-        units, unit = polys, "ring-ops/s"
-        sample = f"{polys} of 1024 polys, same step (NTT, *w, INTT), Shoup butterflies, OpenMP"
-    elif wl in ("m2a", "m2b"):
+def cpu_baseline(wl: str, budget_s: float):
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import oracle as O
+
+    O.use_native_build()  # -O3 -march=native -fopenmp for this host, in a temp dir
+    lib = O.lib()
+    cores = host_cores()
+    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m3a": 10, "m3b": 8, "m4": 12}[wl]
+    n = 256 if wl == "m4" else N_RING
+    moduli = O.gen_crt_basis(n, depth, 51 if wl == "m4" else 24)
+    mod = np.asarray(moduli, dtype=np.uint64)
+    mp = mod.ctypes.data_as(C.POINTER(C.c_uint64))
+    dp = C.POINTER(C.c_double)
+    out = {"kind": "port", "cores": cores, "label": "CPU restatement (oracle/, not OpenFHE), gcc -O3 -march=native -fopenmp"}
+    sig = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_int, C.c_int, dp, C.c_int, dp]
+    if wl in ("m2a", "m2b"):
         r, k, c = (1, 30, 120) if wl == "m2a" else (8, 64, 8)
-        nn = n if wl == "m2a" else n
-        a = O.random_matrix(1, r, k, moduli, nn)
-        b = O.random_matrix(2, k, c, moduli, nn)
+        lib.orc_bench_matmul.restype = C.c_int
+        lib.orc_bench_matmul.argtypes = [C.c_size_t] * 3 + sig
+        fn = lambda ra, sa, ro, so: lib.orc_bench_matmul(r, k, c, depth, n, mp, cores, ra, sa, ro, so)
+        units, unit, width = r * k * c, "ring-ops/s", 1
+        macs = units * n * depth
+        reps_all, reps_one = 9, (3 if macs < 2e9 else 1)
+        sample = f"the full ({r}x{k})*({k}x{c}) product at n=2^14, L={depth}" + ("" if wl == "m2a" else " (an 8x8 output block of the 64x64 product)")
+    elif wl == "m1":
+        polys = 128
+        lib.orc_bench_ring_mul.restype = C.c_int
+        lib.orc_bench_ring_mul.argtypes = [C.c_size_t] + sig
+        fn = lambda ra, sa, ro, so: lib.orc_bench_ring_mul(polys, depth, n, mp, cores, ra, sa, ro, so)
+        units, unit, width = polys, "ring-ops/s", 3
+        reps_all, reps_one = 9, 5
+        sample = f"{polys} of 1024 polys, same step (NTT, *w, INTT), Shoup butterflies + Barrett product"
+    else:
+        return cpu_baseline_preimage(O, wl, n, moduli, cores, budget_s, out)
+    sec_all = np.zeros(reps_all * width, dtype=np.float64)
+    sec_one = np.zeros(reps_one * width, dtype=np.float64)
+    rc = fn(reps_all, sec_all.ctypes.data_as(dp), reps_one, sec_one.ctypes.data_as(dp))
+    assert rc == 0, "CPU baseline allocation failed"
+    t_all = sec_all.reshape(reps_all, width).sum(axis=1)
+    t_one = sec_one.reshape(reps_one, width).sum(axis=1)
+    out.update({"value": units / float(np.median(t_all)), "unit": unit,
+                "median_s": float(np.median(t_all)), "min_s": float(t_all.min()), "reps": reps_all,
+                "one_core": {"value": units / float(np.median(t_one)), "cores": 1, "median_s": float(np.median(t_one)),
+                             "min_s": float(t_one.min()), "reps": reps_one},
+                "sample": sample + "; timed inside C (CLOCK_MONOTONIC), inputs generated in C, median after one warm-up"})
+    if wl == "m1":
+        per = sec_all.reshape(reps_all, width)
+        out["phase_median_s"] = {"ntt": float(np.median(per[:, 0])), "mul": float(np.median(per[:, 1])), "intt": float(np.median(per[:, 2]))}
+    return out
 
-        def run():
-            return O.matmul(a, b, moduli, fast=True)
 
-        units, unit = r * k * c, "ring-ops/s"
-        sample = f"({r}x{k})*({k}x{c}) at n=2^14, L={L}" + ("" if wl == "m2a" else " (8x8 output block of the 64x64 product)")
-    else:  # m3a: the whole preimage chain (oracle.preimage), trapdoor and covariance factors prepared outside
-        base, sigma, cols = 12, 4.578, 4
-        seed = bytes(range(32))
-        r, e, a = O.trapdoor_gen(moduli, n, base, sigma, 1, seed)
-        _, c_par, s_par = O.preimage_params(moduli, n, base, sigma, 1)
-        inv = lambda m: O.matrix_ntt(m, moduli, inverse=True)
-        rt, et = np.swapaxes(r, 0, 1), np.swapaxes(e, 0, 1)
-        cov = O.p1_covariance(inv(O.matmul(r, rt, moduli, fast=True)), inv(O.matmul(r, et, moduli, fast=True)),
-                              inv(O.matmul(e, et, moduli, fast=True)), moduli, c_par, s_par, sigma)
-        target = O.matrix_ntt(O.random_matrix(7, 1, cols, moduli, n), moduli)
+def cpu_baseline_preimage(O, wl, n, moduli, cores, budget_s, out):
+    """oracle.preimage: the whole chain (p2, p1, G-sampling, products, NTTs) with the trapdoor and the covariance
+    factors prepared outside, as on the GPU; the kernels are C/OpenMP, Python only sequences them."""
+    import numpy as np
 
-        def run():
-            return O.preimage(moduli, n, base, sigma, r, e, a, target, seed, cov=cov)
+    base, sigma = (17, 4.578) if wl == "m4" else (12, 4.578)
+    cols = 4
+    seed = bytes(range(32))
+    O.lib().orc_set_threads(cores)
+    r, e, a = O.trapdoor_gen(moduli, n, base, sigma, 1, seed)
+    _, c_par, s_par = O.preimage_params(moduli, n, base, sigma, 1)
+    inv = lambda m: O.matrix_ntt(m, moduli, inverse=True)
+    rt, et = np.swapaxes(r, 0, 1), np.swapaxes(e, 0, 1)
+    cov = O.p1_covariance(inv(O.matmul(r, rt, moduli, fast=True)), inv(O.matmul(r, et, moduli, fast=True)),
+                          inv(O.matmul(e, et, moduli, fast=True)), moduli, c_par, s_par, sigma)
 
-        units, unit = cols, "preimages/s"
-        sample = f"{cols} of 50 target columns per call, same chain (p2, p1, G-sampling, products, NTTs), OpenMP"
-    run()  # warm-up (tables, page faults)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        run()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 100000:
-            break
-    return {"value": units * reps / el, "unit": unit, "cores": cores, "kind": "port",
-            "sample": sample + f"; {reps} reps in {el:.1f} s; CPU restatement (not OpenFHE)"}
+    def timed(cols_, reps):
+        target = O.matrix_ntt(O.random_matrix(7, 1, cols_, moduli, n), moduli)
+        O.preimage(moduli, n, base, sigma, r, e, a, target, seed, cov=cov)  # warm-up
+        ts = []
+        for i in range(reps):
+            t0 = time.perf_counter()
+            O.preimage(moduli, n, base, sigma, r, e, a, target, bytes([i]) + seed[1:], cov=cov)
+            ts.append(time.perf_counter() - t0)
+        return np.asarray(ts)
+
+    t_all = timed(cols, 5)
+    O.lib().orc_set_threads(1)
+    one_cols = 1
+    t_one = timed(one_cols, 3)
+    O.lib().orc_set_threads(cores)
+    out.update({"value": cols / float(np.median(t_all)), "unit": "preimages/s", "median_s": float(np.median(t_all)),
+                "min_s": float(t_all.min()), "reps": 5,
+                "one_core": {"value": one_cols / float(np.median(t_one)), "cores": 1, "median_s": float(np.median(t_one)),
+                             "min_s": float(t_one.min()), "reps": 3, "sample": f"{one_cols} target column per call"},
+                "sample": f"{cols} of 50 target columns per call, same chain (p2, p1, G-sampling, products, NTTs), median of 5 calls after a warm-up"})
+    return out
 
 
 if __name__ == "__main__":

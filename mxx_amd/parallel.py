@@ -55,9 +55,36 @@ def padded_len(total: int, world: int) -> int:
     return -(-total // world)
 
 
+def place_column_blocks(gathered, cols_total: int):
+    """Undo the padding of an all-gathered column-sharded matrix.
+
+    `gathered` has shape (world, rows, padded_cols, ...) - rank r's rows x len(shard r) block sits in
+    gathered[r, :, :len(shard r)], the rest of its columns is padding.  Returns the rows x cols_total
+    matrix (numpy or torch, whatever came in).  The engine-side gather (ColumnAllGather) moves exactly
+    these blocks with copy_block."""
+    world = gathered.shape[0]
+    parts = []
+    for r, sr in enumerate(all_shard_ranges(cols_total, world)):
+        if len(sr):
+            parts.append(gathered[r][:, : len(sr)])
+    if hasattr(gathered, "numpy") and not hasattr(gathered, "__array_interface__"):
+        import torch
+
+        return torch.cat(parts, dim=1)
+    import numpy as np
+
+    return np.concatenate(parts, axis=1)
+
+
 class DeviceBuffer:
     """Zero-copy view of a libgpupoly matrix as a torch tensor (`__cuda_array_interface__`),
-    so RCCL collectives run directly on the engine's HBM allocation."""
+    so RCCL collectives run directly on the engine's HBM allocation.
+
+    Ordering contract (the engine's stream is not torch's): the caller synchronises in BOTH
+    directions - the engine's work that produced the bytes must have completed before a collective
+    reads them (`gpu_device_sync()`), and the collective must have completed (e.g.
+    `torch.cuda.current_stream().synchronize()`) before any engine call writes, frees or re-uses
+    the viewed matrix.  The matrix is kept alive by this object; keep the object alive until then."""
 
     def __init__(self, matrix):
         import ctypes as C
@@ -79,3 +106,58 @@ class DeviceBuffer:
         import torch
 
         return torch.as_tensor(self, device=torch.device("cuda", device_index))
+
+
+class ColumnAllGather:
+    """All-gather of the column blocks of a rows x cols_total matrix that is sharded over the ranks by
+    `shard_range` - the one exchange step of the sharded product / sharded preimage (SURVEY.md 8e;
+    the reference moves these blocks through host bytes, src/sampler/trapdoor/gpu.rs:371-397).
+
+    RCCL reads and writes the engine's own HBM allocations (DeviceBuffer).  With one row and equal
+    shards every rank's block is a contiguous run of the full matrix, which is then the receive
+    buffer itself; otherwise blocks are padded to the largest shard, gathered into a staging matrix
+    and moved into place with copy_block."""
+
+    def __init__(self, params, rows: int, cols_total: int, level: int, torch, dist, device_index: int):
+        from .matrix import GpuDCRTPolyMatrix
+
+        self.torch, self.dist, self.device_index = torch, dist, device_index
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.rows, self.cols_total = rows, cols_total
+        self.ranges = all_shard_ranges(cols_total, self.world)
+        self.padded = padded_len(cols_total, self.world)
+        self.direct = rows == 1 and all(len(r) == self.padded for r in self.ranges)
+        self.full = GpuDCRTPolyMatrix(params, rows, cols_total, level, True)
+        self._full_t = DeviceBuffer(self.full).tensor(device_index)
+        if not self.direct:
+            self._send = GpuDCRTPolyMatrix(params, rows, self.padded, level, True)
+            self._recv = GpuDCRTPolyMatrix(params, self.world * rows, self.padded, level, True)
+            self._send_t = DeviceBuffer(self._send).tensor(device_index)
+            self._recv_t = DeviceBuffer(self._recv).tensor(device_index)
+
+    def gather(self, local):
+        """local: this rank's rows x len(shard) block (EVAL or COEFF).  Returns the full matrix, valid
+        on the engine's stream when this returns."""
+        from ._ffi import gpu_device_sync
+
+        mine = self.ranges[self.rank]
+        assert local.nrow == self.rows and local.ncol == len(mine), "local block does not match this rank's shard"
+        if self.direct:
+            assert local.is_ntt == self.full.is_ntt, "direct gather keeps the full matrix's format tag"
+            gpu_device_sync()  # engine -> collective
+            self.dist.all_gather_into_tensor(self._full_t, DeviceBuffer(local).tensor(self.device_index))
+            self.torch.cuda.current_stream().synchronize()  # collective -> engine
+        else:
+            send_t = self._send_t
+            if len(mine) == self.padded:
+                send_t = DeviceBuffer(local).tensor(self.device_index)  # a full-width shard is its own send buffer
+            elif len(mine):
+                self._send.copy_block_from(local, 0, 0, 0, 0, self.rows, len(mine))
+            gpu_device_sync()
+            self.dist.all_gather_into_tensor(self._recv_t, send_t)
+            self.torch.cuda.current_stream().synchronize()
+            for r, sr in enumerate(self.ranges):
+                if len(sr):
+                    self.full.copy_block_from(self._recv, 0, sr.start, r * self.rows, 0, self.rows, len(sr))
+        self.full.is_ntt = local.is_ntt
+        return self.full

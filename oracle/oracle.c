@@ -539,39 +539,56 @@ static inline uint64_t splitmix64(uint64_t *s) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
 }
+#include <sys/mman.h>
 static uint64_t *bench_random(size_t polys, uint32_t L, uint32_t n, const uint64_t *moduli, uint64_t seed) {
-    uint64_t *m = malloc(sizeof(uint64_t) * polys * L * n);
-    if (!m) return NULL;
-    for (size_t p = 0; p < polys; ++p)
-        for (uint32_t l = 0; l < L; ++l) {
-            uint64_t s = seed ^ (p * 0x100000001b3ull + l);
-            uint64_t *v = m + (p * L + l) * (size_t)n;
-            for (uint32_t i = 0; i < n; ++i) v[i] = splitmix64(&s) % moduli[l];
-        }
+    /* multi-GB operands: 2 MiB-aligned + transparent huge pages keep first-touch faults out of the way */
+    void *raw = NULL;
+    size_t bytes = sizeof(uint64_t) * polys * L * n;
+    if (posix_memalign(&raw, (size_t)2 << 20, bytes ? bytes : 8)) return NULL;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(raw, bytes, MADV_HUGEPAGE);
+#endif
+    uint64_t *m = raw;
+    long total = (long)(polys * L);
+#pragma omp parallel for schedule(static)
+    for (long v = 0; v < total; ++v) {
+        uint32_t l = (uint32_t)(v % L);
+        uint64_t s = seed ^ ((uint64_t)v * 0x100000001b3ull);
+        uint64_t *x = m + (size_t)v * n;
+        for (uint32_t i = 0; i < n; ++i) x[i] = (uint64_t)(((u128)splitmix64(&s) * moduli[l]) >> 64);  /* uniform in [0, q) */
+    }
     return m;
 }
 
-/* (rows x inner) * (inner x cols) in EVAL form; sec[r] = seconds of repetition r (after one warm-up) */
-int orc_bench_matmul(size_t rows, size_t inner, size_t cols, uint32_t L, uint32_t n, const uint64_t *moduli, int reps,
-                     double *sec) {
+/* (rows x inner) * (inner x cols) in EVAL form, inputs generated once; after one warm-up, reps_all
+ * repetitions on `threads` threads (sec_all) and reps_one repetitions on one thread (sec_one) */
+int orc_bench_matmul(size_t rows, size_t inner, size_t cols, uint32_t L, uint32_t n, const uint64_t *moduli, int threads,
+                     int reps_all, double *sec_all, int reps_one, double *sec_one) {
+    orc_set_threads(threads);
     uint64_t *a = bench_random(rows * inner, L, n, moduli, 0x6d7878 ^ 4), *b = bench_random(inner * cols, L, n, moduli, 0x6d7878 ^ 5);
     uint64_t *c = malloc(sizeof(uint64_t) * rows * cols * L * n);
     if (!a || !b || !c) { free(a); free(b); free(c); return 1; }
     orc_matmul_fast(c, a, b, rows, inner, cols, L, n, moduli);
-    for (int r = 0; r < reps; ++r) {
+    for (int r = 0; r < reps_all; ++r) {
         double t0 = now_s();
         orc_matmul_fast(c, a, b, rows, inner, cols, L, n, moduli);
-        sec[r] = now_s() - t0;
+        sec_all[r] = now_s() - t0;
     }
+    orc_set_threads(1);
+    for (int r = 0; r < reps_one; ++r) {
+        double t0 = now_s();
+        orc_matmul_fast(c, a, b, rows, inner, cols, L, n, moduli);
+        sec_one[r] = now_s() - t0;
+    }
+    orc_set_threads(threads);
     free(a); free(b); free(c);
     return 0;
 }
 
 /* workload M1 on `polys` polynomials: x <- INTT(NTT(x) o w); sec[3*r + {0,1,2}] = forward NTT,
- * pointwise product, inverse NTT of repetition r */
-int orc_bench_ring_mul(size_t polys, uint32_t L, uint32_t n, const uint64_t *moduli, int reps, double *sec) {
-    uint64_t *x = bench_random(polys, L, n, moduli, 0x6d7878 ^ 2), *w = bench_random(1, L, n, moduli, 0x6d7878 ^ 3);
-    if (!x || !w) { free(x); free(w); return 1; }
+ * pointwise product, inverse NTT of repetition r; same all-threads / one-thread split */
+static void ring_mul_reps(uint64_t *x, const uint64_t *w, size_t polys, uint32_t L, uint32_t n, const uint64_t *moduli,
+                          int reps, double *sec) {
     for (int r = -1; r < reps; ++r) {
         double t0 = now_s();
         orc_matrix_ntt(x, polys, L, n, moduli, 0);
@@ -582,6 +599,16 @@ int orc_bench_ring_mul(size_t polys, uint32_t L, uint32_t n, const uint64_t *mod
         double t3 = now_s();
         if (r >= 0) { sec[3 * r] = t1 - t0; sec[3 * r + 1] = t2 - t1; sec[3 * r + 2] = t3 - t2; }
     }
+}
+int orc_bench_ring_mul(size_t polys, uint32_t L, uint32_t n, const uint64_t *moduli, int threads, int reps_all,
+                       double *sec_all, int reps_one, double *sec_one) {
+    orc_set_threads(threads);
+    uint64_t *x = bench_random(polys, L, n, moduli, 0x6d7878 ^ 2), *w = bench_random(1, L, n, moduli, 0x6d7878 ^ 3);
+    if (!x || !w) { free(x); free(w); return 1; }
+    ring_mul_reps(x, w, polys, L, n, moduli, reps_all, sec_all);
+    orc_set_threads(1);
+    ring_mul_reps(x, w, polys, L, n, moduli, reps_one, sec_one);
+    orc_set_threads(threads);
     free(x); free(w);
     return 0;
 }

@@ -37,6 +37,28 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def use_native_build() -> str:
+    """bench.py's cpu_baseline leg: compile the same sources with -march=native for THIS host into a
+    temp dir and make lib() load that build (the in-tree liboracle.so is a portable build that also
+    travels to other machines).  Must be called before the first lib()."""
+    global _LIB_PATH, _lib
+    import tempfile
+
+    if "liboracle_native" in _LIB_PATH:
+        return _LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_native_build() must run before the library is first loaded")
+    out = os.path.join(tempfile.mkdtemp(prefix="oracle_native_"), "liboracle_native.so")
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle_sampling.c")]
+    subprocess.check_call(
+        ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=gnu11", "-ffp-contract=off", "-shared", "-o", out]
+        + srcs
+        + ["-lm"]
+    )
+    _LIB_PATH = out
+    return out
+
+
 _lib = None
 _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)

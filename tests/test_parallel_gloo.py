@@ -8,7 +8,11 @@ import textwrap
 
 import pytest
 
-from mxx_amd.parallel import all_shard_ranges, padded_len, shard_range
+import json
+
+import numpy as np
+
+from mxx_amd.parallel import all_shard_ranges, padded_len, place_column_blocks, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -33,7 +37,7 @@ WORKER = textwrap.dedent(
     import numpy as np
     import torch
     import torch.distributed as dist
-    from mxx_amd.parallel import shard_range, all_gather_column_blocks, padded_len
+    from mxx_amd.parallel import shard_range, all_gather_column_blocks, padded_len, place_column_blocks
     from oracle import oracle as O
 
     dist.init_process_group(backend="gloo")
@@ -53,6 +57,17 @@ WORKER = textwrap.dedent(
     full = np.concatenate([b.numpy().view(np.uint64).reshape(2, -1, len(moduli), n) for b in blocks], axis=1)
     want = O.matmul(A, B, moduli)
     assert np.array_equal(full, want), "gathered product differs"
+    # unequal shards (7 columns over 2 ranks -> 4 + 3): pad to the largest shard, gather, un-pad with the
+    # same placement rule ColumnAllGather applies on the device (bench.py --scaling strong)
+    B7 = O.matrix_ntt(O.random_matrix(3, 3, 7, moduli, n), moduli)
+    s7 = shard_range(7, world, rank)
+    pad = padded_len(7, world)
+    block = np.zeros((2, pad, len(moduli), n), dtype=np.uint64)
+    block[:, : len(s7)] = O.matmul(A, np.ascontiguousarray(B7[:, s7.start:s7.stop]), moduli)
+    recv = torch.empty(world * block.size, dtype=torch.int64)
+    dist.all_gather_into_tensor(recv, torch.from_numpy(block.reshape(-1).view(np.int64)))
+    full7 = place_column_blocks(recv.numpy().view(np.uint64).reshape((world,) + block.shape), 7)
+    assert np.array_equal(full7, O.matmul(A, B7, moduli)), "padded gather differs"
     # preimage-style column sharding: 50 target columns, every column owned exactly once
     owned = torch.zeros(50, dtype=torch.int64)
     s = shard_range(50, world, rank)
@@ -83,3 +98,26 @@ def test_world_size_2_gloo(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "GLOO_OK True" in out.stdout
+
+
+def test_place_column_blocks_unpads():
+    world, rows, total = 3, 2, 8
+    full = np.arange(rows * total * 5).reshape(rows, total, 5)
+    pad = padded_len(total, world)
+    g = np.full((world, rows, pad, 5), -1)
+    for r, sr in enumerate(all_shard_ranges(total, world)):
+        g[r, :, : len(sr)] = full[:, sr.start : sr.stop]
+    assert np.array_equal(place_column_blocks(g, total), full)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun and no RANK/WORLD_SIZE in the environment must spawn two ranks
+    that reach init_process_group (gloo + --dry-run here: no GPU in this container) and all-reduce."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--dist-backend", "gloo"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    assert got == {"dry_run": True, "world": 2, "all_reduce": 2.0, "backend": "gloo"}
