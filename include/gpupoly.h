@@ -157,6 +157,10 @@ int gpupoly_timer_mark(GpuContext *ctx, uint32_t slot);
 int gpupoly_timer_elapsed(GpuContext *ctx, uint32_t slot_begin, uint32_t slot_end, float *out_ms);
 /* raw device pointer / byte size of a matrix (zero-copy interop, e.g. RCCL).  */
 int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, size_t *out_bytes);
+/* Replica of `src` in another context (same ring; any device): one device-to-device / peer copy over
+ * xGMI, ordered on both contexts' streams - replaces the reference's host round trip
+ * to_cpu_staging_bytes -> from_cpu_staging_bytes (src/lookup/ggh15/pubkey_gpu.rs:153-196).     */
+int gpupoly_matrix_copy_to_context(GpuContext *dst_ctx, const GpuMatrix *src, GpuMatrix **out);
 int gpupoly_context_device(const GpuContext *ctx, int *out_device);
 int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes);
 const char *gpupoly_version(void);

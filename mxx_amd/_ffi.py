@@ -99,6 +99,7 @@ SIGNATURES = {
     "gpupoly_timer_mark": (C.c_int, [_vp, C.c_uint32]),
     "gpupoly_timer_elapsed": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "gpupoly_matrix_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "gpupoly_matrix_copy_to_context": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "gpupoly_context_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_context_word_bytes": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_version": (C.c_char_p, []),

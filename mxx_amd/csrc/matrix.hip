@@ -250,6 +250,74 @@ extern "C" int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, s
     return 0;
 }
 
+// ---- device-to-device replica transport (extension) --------------------------
+// The reference moves a matrix to another device's context through host bytes
+// (to_cpu_staging_bytes -> from_cpu_staging_bytes, src/lookup/ggh15/pubkey_gpu.rs:153-196); its only peer
+// copies are the int64 p1 buffer (cuda/src/matrix/MatrixTrapdoor.cu:2816,3422).  Here the replica is one
+// peer copy over xGMI (hipMemcpyPeerAsync), ordered on both streams: the copy waits for whatever the source
+// context has enqueued on the matrix, and the source context's later work (including a stream-ordered free
+// of the source) waits for the copy.
+extern "C" int gpupoly_matrix_copy_to_context(GpuContext *dst_ctx, const GpuMatrix *src, GpuMatrix **out) {
+    ABI_GUARD_BEGIN
+    if (!dst_ctx || !src || !out) return set_error("gpupoly_matrix_copy_to_context: null argument");
+    *out = nullptr;
+    GpuContext *sctx = src->ctx;
+    if (dst_ctx->N != sctx->N || dst_ctx->wide != sctx->wide || src->level >= dst_ctx->limb_count)
+        return set_error("gpupoly_matrix_copy_to_context: ring mismatch between the contexts");
+    for (int l = 0; l <= src->level; ++l)
+        if (dst_ctx->moduli[l] != sctx->moduli[l])
+            return set_error("gpupoly_matrix_copy_to_context: modulus mismatch between the contexts");
+    GpuMatrix *dst = nullptr;
+    if (int rc = gpu_matrix_create(dst_ctx, src->level, src->rows, src->cols, src->format, &dst)) return rc;
+    if (src->bytes == 0) {
+        *out = dst;
+        return 0;
+    }
+    hipEvent_t ready = nullptr, done = nullptr;
+    auto fail = [&](hipError_t e, const char *what) {
+        if (ready) (void)hipEventDestroy(ready);
+        if (done) (void)hipEventDestroy(done);
+        gpu_matrix_destroy(dst);
+        return set_error(e, what);
+    };
+    hipError_t e = hipSetDevice(sctx->device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ready, sctx->stream);
+    if (e != hipSuccess) return fail(e, "source event");
+    e = hipSetDevice(dst_ctx->device);
+    if (e != hipSuccess) return fail(e, "hipSetDevice");
+    if (dst_ctx->device != sctx->device) {
+        int can = 0;
+        e = hipDeviceCanAccessPeer(&can, dst_ctx->device, sctx->device);
+        if (e != hipSuccess) return fail(e, "hipDeviceCanAccessPeer");
+        if (can) {
+            e = hipDeviceEnablePeerAccess(sctx->device, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) {
+                (void)hipGetLastError();
+                e = hipSuccess;
+            }
+            if (e != hipSuccess) return fail(e, "hipDeviceEnablePeerAccess");
+        }  // without peer access hipMemcpyPeerAsync stages through the host by itself
+    }
+    e = hipStreamWaitEvent(dst_ctx->stream, ready, 0);
+    if (e == hipSuccess) {
+        e = dst_ctx->device == sctx->device
+                ? hipMemcpyAsync(dst->data, src->data, src->bytes, hipMemcpyDeviceToDevice, dst_ctx->stream)
+                : hipMemcpyPeerAsync(dst->data, dst_ctx->device, src->data, sctx->device, src->bytes, dst_ctx->stream);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(done, dst_ctx->stream);
+    if (e != hipSuccess) return fail(e, "peer copy");
+    e = hipSetDevice(sctx->device);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sctx->stream, done, 0);
+    if (e != hipSuccess) return fail(e, "source stream wait");
+    (void)hipEventDestroy(ready);  // destruction is deferred by the runtime until the events complete
+    (void)hipEventDestroy(done);
+    *out = dst;
+    return 0;
+    ABI_GUARD_END
+}
+
 // ---- ABI: RNS batch load/store (MatrixSerde.cu:566-924 behaviour) -----------------------------
 static int make_event_set(GpuContext *ctx, GpuEventSet **out_events) {
     GpuEventSet *set = new GpuEventSet();

@@ -340,6 +340,20 @@ class GpuDCRTPolyMatrix:
             check_status(_ffi.lib().gpu_matrix_copy(out.raw, self.raw), "gpu_matrix_copy")
         return out
 
+    def to_params(self, params) -> "GpuDCRTPolyMatrix":
+        """Replica of this matrix in the context of `params` (another device's, usually): one peer copy over
+        xGMI instead of the reference's `to_cpu_staging_bytes` -> `from_cpu_staging_bytes` host round trip
+        (src/lookup/ggh15/pubkey_gpu.rs:153-196)."""
+        if params.ctx_raw().value == self.params.ctx_raw().value:
+            return self.clone()
+        out = object.__new__(GpuDCRTPolyMatrix)
+        raw = C.c_void_p()
+        check_status(_ffi.lib().gpupoly_matrix_copy_to_context(params.ctx_raw(), self.raw, C.byref(raw)),
+                     "gpupoly_matrix_copy_to_context")
+        out.params, out.nrow, out.ncol, out.level, out.is_ntt, out.raw = params, self.nrow, self.ncol, self.level, self.is_ntt, raw
+        out._finalizer = weakref.finalize(out, _ffi.lib().gpu_matrix_destroy, raw)
+        return out
+
     def size(self):
         return self.nrow, self.ncol
 

@@ -59,6 +59,12 @@ class GpuDCRTTrapdoor:
             self._p1_cache = ((c, s, dgg_stddev), cache)
             return cache
 
+    def to_params(self, params) -> "GpuDCRTTrapdoor":
+        """Replica of the trapdoor on another device context: two peer copies (R, E) and the small products
+        recomputed there - instead of trapdoor_to_bytes / trapdoor_from_bytes through the host
+        (src/lookup/ggh15/pubkey_gpu.rs:153-196)."""
+        return GpuDCRTTrapdoor(self.r.to_params(params), self.e.to_params(params))
+
     def to_compact_bytes(self) -> bytes:
         """R then E, each as u64-LE length + compact matrix bytes (gpu.rs:82-97)."""
         out = b""
@@ -158,5 +164,26 @@ class GpuDCRTPolyTrapdoorSampler:
 
     def preimage_batched_sharded(self, requests):
         """`preimage_batched_sharded` (gpu.rs:371-397): requests = [(entry_idx, params, trapdoor, A, target)];
-        each request runs on the device its params name."""
-        return [(idx, self.preimage(p, td, a, t)) for (idx, p, td, a, t) in requests]
+        every request runs on the device context its params name, and the contexts work concurrently - the
+        reference fans out with rayon's `into_par_iter`; here one worker thread per distinct context issues that
+        context's requests in order (the ABI calls release the GIL and never block the host, so the devices'
+        streams fill in parallel).  Results come back in request order, like rayon's collect."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        groups: dict = {}
+        for pos, req in enumerate(requests):
+            groups.setdefault(req[1].ctx_raw().value, []).append((pos, req))
+        results = [None] * len(requests)
+
+        def run(items):
+            for pos, (idx, p, td, a, t) in items:
+                results[pos] = (idx, self.preimage(p, td, a, t))
+
+        if len(groups) <= 1:
+            for items in groups.values():
+                run(items)
+            return results
+        with ThreadPoolExecutor(max_workers=len(groups)) as pool:
+            for f in [pool.submit(run, items) for items in groups.values()]:
+                f.result()  # re-raises a worker's exception
+        return results

@@ -5,6 +5,7 @@ sizes in seconds, so parity is carried by exact algebraic identities on device-s
   M2b  config 3                (n=2^14, L=8, 64x64): G * G^-1(M) == M through the fused decompose and the
                                streamed product with inner dimension 1024; (A*B)*C == A*(B*C)
   M3a  bench_preimage shape    (n=2^14, L=10, 50 columns): A*x == u and the limb-0 infinity norm of x
+  M3b  config 3 of BASELINE    (the same at L=8)
 """
 import math
 
@@ -50,8 +51,9 @@ def test_m2b_gadget_inverse_and_associativity(gpu, oracle):
     assert int(d_small.max()) < (1 << 12)
 
 
-def test_m3a_preimage_relation_and_norm(gpu, oracle):
-    p = make_params(gpu, oracle, N, 10, 24, 12)
+@pytest.mark.parametrize("depth", [10, 8])  # bench_preimage_gpu.rs shape (M3a) and BASELINE configs[3] (M3b, L = 8)
+def test_m3_preimage_relation_and_norm(gpu, oracle, depth):
+    p = make_params(gpu, oracle, N, depth, 24, 12)
     sigma, base = 4.578, 12
     sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, sigma)
     td, A = sampler.trapdoor(p, 1)

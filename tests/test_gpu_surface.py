@@ -1,0 +1,191 @@
+"""GPU: ABI entries and wrapper methods that are bound but were not exercised anywhere else, BASELINE configs[0]
+at its own size, and the Rust wrapper's add -> retag -> ntt sequence replayed through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import make_params, rand_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _seed(gpu, i):
+    return gpu.GpuRngSeed.from_bytes(bytes([(i * 29 + j) & 0xFF for j in range(32)]))
+
+
+@pytest.mark.parametrize("d,n,bits,cols", [(1, 64, 24, 3), (2, 32, 51, 2), (5, 16, 24, 2)])
+def test_sample_p1_full_equals_cached(gpu, oracle, d, n, bits, cols):
+    """gpu_matrix_sample_p1_full (cuda/include/matrix/MatrixTrapdoor.cuh:66-101; declared, not bound by the Rust
+    side): factorisation + sampling in one call == covariance cache + sample_p1_full_cached, same seed."""
+    from mxx_amd import _ffi
+
+    base = 12 if bits == 24 else 17
+    p = make_params(gpu, oracle, n, 2, bits, base)
+    moduli = p.moduli()
+    rng = np.random.default_rng(d * 7 + n)
+
+    def small(rows, c, bound):
+        v = rng.integers(-bound, bound + 1, size=(rows, c, n))
+        return np.stack([np.mod(v, q).astype(np.uint64) for q in moduli], axis=-2)
+
+    r, e = small(d, 2 * d, 6), small(d, 2 * d, 6)
+    gr, ge = gpu.GpuDCRTPolyMatrix.from_rns(p, r, False), gpu.GpuDCRTPolyMatrix.from_rns(p, e, False)
+    gr.ntt_all_in_place()
+    ge.ntt_all_in_place()
+    a = (gr * gr.transpose()).into_coeff_domain()
+    b = (gr * ge.transpose()).into_coeff_domain()
+    dm = (ge * ge.transpose()).into_coeff_domain()
+    tp2 = gpu.GpuDCRTPolyMatrix.from_rns(p, small(2 * d, cols, 2000), False)
+    sigma, s_par, dgg = 4.578 * 4097, 9.0e6, 4.578
+    seed = _seed(gpu, 3)
+    cache = gpu.GpuDCRTPolyMatrix.create_p1_covariance_cache(a, b, dm, sigma, s_par, dgg)
+    want = gpu.GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2.clone(), seed)
+    out = gpu.GpuDCRTPolyMatrix.new_empty(p, 2 * d, cols)
+    st = _ffi.lib().gpu_matrix_sample_p1_full(a.raw, b.raw, dm.raw, tp2.raw, sigma, s_par, dgg, seed, out.raw)
+    _ffi.check_status(st, "gpu_matrix_sample_p1_full")
+    out.is_ntt = True
+    assert out == want
+
+
+def test_poly_compact_bytes_aliases(gpu, oracle):
+    """gpu_poly_{store,load}_compact_bytes: the 1x1 aliases of the matrix entry points (MatrixSerde.cuh:10-58)."""
+    from mxx_amd import _ffi
+
+    n = 128
+    p = make_params(gpu, oracle, n, 2, 24, 12)
+    moduli = p.moduli()
+    coeff = rand_matrix(oracle, 301, 1, 1, moduli, n)
+    lib = _ffi.lib()
+
+    def store(fn, m):
+        cap = n * 16 + 16
+        buf = (C.c_uint8 * cap)()
+        bits, bpc, ln = C.c_uint16(0), C.c_uint16(0), C.c_size_t(0)
+        _ffi.check_status(fn(m.raw, buf, cap, C.byref(bits), C.byref(bpc), C.byref(ln)), "store_compact_bytes")
+        return bytes(buf[: ln.value]), bits.value, bpc.value
+
+    m1 = gpu.GpuDCRTPolyMatrix.from_rns(p, coeff, False)
+    m2 = gpu.GpuDCRTPolyMatrix.from_rns(p, coeff, False)
+    got = store(lib.gpu_poly_store_compact_bytes, m1)
+    assert got == store(lib.gpu_matrix_store_compact_bytes, m2)
+    assert got == oracle.compact_payload(coeff, moduli)
+    back = gpu.GpuDCRTPolyMatrix.new_empty(p, 1, 1)
+    payload = (C.c_uint8 * len(got[0])).from_buffer_copy(got[0])
+    _ffi.check_status(lib.gpu_poly_load_compact_bytes(back.raw, payload, len(got[0]), got[1]), "gpu_poly_load_compact_bytes")
+    back.is_ntt = False
+    assert np.array_equal(back.to_rns(), coeff)
+
+
+@pytest.mark.parametrize("n,depth,bits,base", [(128, 2, 24, 12), (64, 3, 17, 5), (32, 2, 51, 17)])
+def test_mul_decompose_small_and_column_helpers(gpu, oracle, n, depth, bits, base):
+    """mul_decompose_small, get_column_matrix_decompose, mul_tensor_identity_decompose
+    (src/matrix/gpu_dcrt_poly.rs:1495-1579) against the CPU restatement's decompose + product."""
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    k = p.modulus_digits()
+    ks = -(-bits // base)
+    rows_b, cols_b = 2, 3
+    # small-norm B (the small variants assume |B| < min q_i: limb 0 carries the value, matrix/mod.rs:251-255)
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, 1 << (bits - 2), size=(rows_b, cols_b, n))
+    b_small = np.stack([np.mod(v, q).astype(np.uint64) for q in moduli], axis=-2)
+    s_small = oracle.matrix_ntt(rand_matrix(oracle, 7, 2, rows_b * ks, moduli, n), moduli)
+    gs = gpu.GpuDCRTPolyMatrix.from_rns(p, s_small, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b_small, False)
+    dec_small = oracle.matrix_ntt(oracle.decompose(b_small, moduli, base, small=True), moduli)
+    assert np.array_equal(gs.mul_decompose_small(gb).to_rns(), oracle.matmul(s_small, dec_small, moduli))
+    # full-gadget column helper
+    b = rand_matrix(oracle, 8, rows_b, cols_b, moduli, n)
+    gbf = gpu.GpuDCRTPolyMatrix.from_rns(p, b, False)
+    dec = oracle.matrix_ntt(oracle.decompose(b, moduli, base), moduli)
+    for j in range(cols_b):
+        assert np.array_equal(gbf.get_column_matrix_decompose(j).to_rns(), dec[:, j : j + 1])
+    # S * (I_m (x) G^-1(B)): block i of S (rows_b*k columns) times every decomposed column of B
+    ident = 2
+    s = oracle.matrix_ntt(rand_matrix(oracle, 9, 2, rows_b * k * ident, moduli, n), moduli)
+    gS = gpu.GpuDCRTPolyMatrix.from_rns(p, s, True)
+    got = gS.mul_tensor_identity_decompose(gbf.ensure_eval(), ident)
+    w = rows_b * k
+    want = np.concatenate([oracle.matmul(np.ascontiguousarray(s[:, i * w : (i + 1) * w]), dec, moduli) for i in range(ident)], axis=1)
+    assert np.array_equal(got.to_rns(), want)
+
+
+def test_add_then_ntt_as_the_rust_wrapper_sequences_it(gpu, oracle):
+    """The Rust wrapper's `add` calls gpu_matrix_add and then copies the rhs's domain flag into its own
+    (src/matrix/gpu_dcrt_poly.rs:406-408); a later ntt_all_in_place must really transform.  The reference's C side
+    tags the sum EVAL whatever the operands were (MatrixArith.cu:2694), which would turn that NTT into a no-op on
+    coefficient-domain data; here add/sub keep the operands' tag, so the sequence
+    add(COEFF, COEFF) -> ntt_all gives NTT(a + b)."""
+    from mxx_amd import _ffi
+
+    n = 256
+    p = make_params(gpu, oracle, n, 2, 24, 12)
+    moduli = p.moduli()
+    a, b = rand_matrix(oracle, 51, 2, 2, moduli, n), rand_matrix(oracle, 52, 2, 2, moduli, n)
+    ga, gb = gpu.GpuDCRTPolyMatrix.from_rns(p, a, False), gpu.GpuDCRTPolyMatrix.from_rns(p, b, False)
+    lib = _ffi.lib()
+    out = gpu.GpuDCRTPolyMatrix.new_empty(p, 2, 2)          # created EVAL, like new_empty on the Rust side
+    _ffi.check_status(lib.gpu_matrix_add(out.raw, ga.raw, gb.raw), "gpu_matrix_add")
+    out.is_ntt = gb.is_ntt                                  # gpu_dcrt_poly.rs:406-408
+    _ffi.check_status(lib.gpu_matrix_ntt_all(out.raw), "gpu_matrix_ntt_all")
+    out.is_ntt = True
+    want = oracle.matrix_ntt(oracle.pointwise("add", a, b, moduli), moduli)
+    assert np.array_equal(out.to_rns(), want)
+    # and the same through sub, then back
+    _ffi.check_status(lib.gpu_matrix_sub(out.raw, ga.raw, gb.raw), "gpu_matrix_sub")
+    out.is_ntt = gb.is_ntt
+    assert np.array_equal(out.to_rns(), oracle.pointwise("sub", a, b, moduli))
+
+
+def test_config0_plumbing_shape_against_the_oracle(gpu, oracle):
+    """BASELINE.json configs[0]: n = 2^12, 2 RNS limbs, 4x4 * 4x4 (the CPU bench's plumbing case) - small enough
+    for the CPU restatement: product, decompose and G * G^-1 on that ring, bit for bit."""
+    n = 4096
+    p = make_params(gpu, oracle, n, 2, 24, 12)
+    moduli = p.moduli()
+    a = oracle.matrix_ntt(rand_matrix(oracle, 401, 4, 4, moduli, n), moduli)
+    b = oracle.matrix_ntt(rand_matrix(oracle, 402, 4, 4, moduli, n), moduli)
+    ga, gb = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True), gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    prod = ga * gb
+    want = oracle.matmul(a, b, moduli)
+    assert np.array_equal(prod.to_rns(), want)
+    coeff = oracle.matrix_ntt(want, moduli, inverse=True)
+    assert np.array_equal(prod.to_coeff_rns(), coeff)
+    dec = prod.decompose()
+    assert np.array_equal(dec.to_rns(), oracle.matrix_ntt(oracle.decompose(coeff, moduli, 12), moduli))
+    assert gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 4) * dec == prod
+
+
+def test_copy_to_context_and_sharded_preimages_two_contexts_one_device(gpu, oracle):
+    """Device-to-device replica transport (gpupoly_matrix_copy_to_context) and the concurrent fan-out of
+    preimage_batched_sharded (src/sampler/trapdoor/gpu.rs:371-397), rehearsed with two contexts on the one GPU
+    this box has (the driver's 8-GPU node gives them different devices; `params_for_device` names them)."""
+    n = 256
+    p0 = make_params(gpu, oracle, n, 2, 24, 12)
+    moduli = p0.moduli()
+    # a second context on the same device: same ring, different dnum -> its own context / stream / cache
+    p1 = gpu.GpuDCRTPolyParams(n, moduli, 12, gpu_ids=p0.gpu_ids(), dnum=2)
+    assert p1.ctx_raw().value != p0.ctx_raw().value
+    assert p0.params_for_device(p0.gpu_ids()[0]).ctx().device() == p0.ctx().device()
+    x = rand_matrix(oracle, 600, 3, 2, moduli, n)
+    m0 = gpu.GpuDCRTPolyMatrix.from_rns(p0, x, False)
+    m0.ntt_all_in_place()                      # still in flight on context 0's stream when the copy is enqueued
+    m1 = m0.to_params(p1)
+    assert m1.params is p1 and m1.is_ntt and np.array_equal(m1.to_rns(), oracle.matrix_ntt(x, moduli))
+    del m0                                     # stream-ordered free of the source after the copy
+    assert np.array_equal((m1 + m1).to_rns(), oracle.pointwise("add", oracle.matrix_ntt(x, moduli), oracle.matrix_ntt(x, moduli), moduli))
+    # trapdoor replica + sharded preimages: requests alternate between the two contexts
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p0, 4.578)
+    td0, a0 = sampler.trapdoor(p0, 1)
+    td1, a1 = td0.to_params(p1), a0.to_params(p1)
+    assert td1.r.params is p1 and np.array_equal(td1.a_mat_coeff.to_rns(), td0.a_mat_coeff.to_rns())
+    us = gpu.GpuDCRTPolyUniformSampler()
+    reqs = []
+    for i in range(6):
+        p, td, a = (p0, td0, a0) if i % 2 == 0 else (p1, td1, a1)
+        reqs.append((100 + i, p, td, a, us.sample_uniform(p, 1, 2 + i % 3, gpu.DistType.FinRingDist())))
+    outs = sampler.preimage_batched_sharded(reqs)
+    assert [idx for idx, _ in outs] == [100 + i for i in range(6)]
+    for (idx, xx), (_, p, td, a, t) in zip(outs, reqs):
+        assert xx.params is p and a * xx == t
