@@ -148,6 +148,9 @@ int gpu_poly_load_compact_bytes(GpuMatrix *poly, const uint8_t *payload, size_t 
 /* Fused S * G^-1(B): never materialises the k-times larger digit matrix
  * (replaces the Rust-side loop src/matrix/gpu_dcrt_poly.rs:1414-1493).       */
 int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);
+/* out <- INTT(lhs o scalar_1x1): the point-wise product rides in the inverse transform's load (one HBM round
+ * trip instead of two; replaces gpu_matrix_mul_scalar + gpu_matrix_intt_all).  out may be lhs.           */
+int gpupoly_matrix_mul_scalar_intt(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *scalar_1x1);
 /* hipEvent timing on the context's compute stream (bench.py's roofline leg). */
 int gpupoly_timer_start(GpuContext *ctx);
 int gpupoly_timer_stop(GpuContext *ctx, float *out_ms);

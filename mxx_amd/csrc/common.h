@@ -182,6 +182,8 @@ int launch_ntt_lds_u32(GpuContext *ctx, uint32_t *data, size_t vectors, uint32_t
 int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff, size_t out_vectors, uint32_t L,
                           uint32_t src_cols, uint32_t towers, uint32_t dpt, uint32_t base_bits, size_t k);
 int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t L, bool inverse);
+// out <- INTT(in o w), w one resident EVAL-form ring element [L][N]; -1: no fused kernel for this context
+int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, const uint32_t *w, size_t vectors, uint32_t L);
 int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
 int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // -1: shape not supported
 int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,

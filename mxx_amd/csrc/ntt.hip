@@ -214,3 +214,37 @@ extern "C" int gpu_matrix_intt_all(GpuMatrix *mat) {
     return 0;
     ABI_GUARD_END
 }
+
+// out <- INTT(lhs o scalar): the point-wise product by a resident 1x1 EVAL ring element rides in the
+// inverse transform's load (extension; the reference runs gpu_matrix_mul_scalar then gpu_matrix_intt_all,
+// two full HBM round trips).  `out` may be `lhs`.  Falls back to those two calls where no fused kernel exists.
+extern "C" int gpupoly_matrix_mul_scalar_intt(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *scalar) {
+    ABI_GUARD_BEGIN
+    if (!scalar) return set_error("gpupoly_matrix_mul_scalar_intt: null scalar");
+    if (matrix_check_same_shape(out, lhs, "gpupoly_matrix_mul_scalar_intt")) return 1;
+    if (scalar->ctx != lhs->ctx || scalar->level != lhs->level)
+        return set_error("gpupoly_matrix_mul_scalar_intt: context/level mismatch");
+    if (scalar->rows != 1 || scalar->cols != 1) return set_error("gpupoly_matrix_mul_scalar_intt: scalar must be 1x1");
+    if (lhs->format != GPU_POLY_FORMAT_EVAL || scalar->format != GPU_POLY_FORMAT_EVAL)
+        return set_error("gpupoly_matrix_mul_scalar_intt requires Eval format");
+    GpuContext *ctx = out->ctx;
+    if (matrix_polys(out) == 0) {
+        out->format = GPU_POLY_FORMAT_COEFF;
+        return 0;
+    }
+    if (ctx_activate(ctx)) return 1;
+    int rc = -1;
+    if (!ctx->wide)
+        rc = launch_mul_intt_u32(ctx, static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
+                                 static_cast<const uint32_t *>(scalar->data), matrix_polys(out) * matrix_limbs(out),
+                                 static_cast<uint32_t>(matrix_limbs(out)));
+    if (rc < 0) {
+        rc = gpu_matrix_mul_scalar(out, lhs, scalar);
+        if (!rc) rc = gpu_matrix_intt_all(out);
+        return rc;
+    }
+    if (rc) return rc;
+    out->format = GPU_POLY_FORMAT_COEFF;
+    return 0;
+    ABI_GUARD_END
+}

@@ -163,10 +163,13 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
 }
 
 // SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)
-template <typename W, bool SGN>
+// MULW: the transform's load multiplies by a resident EVAL-form ring element first (mulw = {w, Shoup(w)} per
+// limb and slot, `in` = the EVAL operand): data <- INTT(in o w) with one kernel instead of a point-wise pass
+// (a full HBM round trip) followed by the transform - gpupoly_matrix_mul_scalar_intt.
+template <typename W, bool SGN, bool MULW = false>
 __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
     inv_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
-               uint32_t L) {
+               uint32_t L, const W *in = nullptr, const TwPair<W> *__restrict__ mulw = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *xs = reinterpret_cast<W *>(smem);
     typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
@@ -189,9 +192,18 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
         const uint32_t B = 8u * grp + wave;
         W v[8];
         {   // stages 13,12,11 on 8 contiguous words per lane, straight from HBM
-            const W *src = g + B * BLK + 8 * lane;
+            const W *src = (MULW ? in + vec * N : g) + B * BLK + 8 * lane;
 #pragma unroll
             for (int m = 0; m < 8; m += VN) *reinterpret_cast<V16 *>(&v[m]) = *reinterpret_cast<const V16 *>(src + m);
+            if constexpr (MULW) {
+                const TwPair<W> *wp = mulw + static_cast<size_t>(limb) * N + B * BLK + 8 * lane;
+                TwPair<W> wv[8];
+#pragma unroll
+                for (int m = 0; m < 8; m += VN / 2)
+                    *reinterpret_cast<V16 *>(&wv[m]) = *reinterpret_cast<const V16 *>(wp + m);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = mul_shoup<W>(v[m], wv[m].w, wv[m].ws, q);  // canonical, as loaded
+            }
             if constexpr (SGN) {  // canonical inputs (exponent 0); keep exponents <= 2
                 gs_network_signed<3, false>(v, tw, B * 64u + lane, 11, q, lc);
                 gs_fold_signed<3, 0, 2>(v, q, muw);

@@ -11,6 +11,10 @@ int launch_ntt_lds_u32(GpuContext *ctx, uint32_t *data, size_t vectors, uint32_t
     return dispatch_ntt_lds(ctx, data, vectors, L, inverse);
 }
 
+int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, const uint32_t *w, size_t vectors, uint32_t L) {
+    return launch_mul_intt(ctx, out, in, w, vectors, L);
+}
+
 // decompose + forward NTT in one pass (ntt14.h, fwd_digits_kernel); -1: not available for this
 // context / path override, the caller then runs the digit kernel and the transform separately
 int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff, size_t out_vectors, uint32_t L,

@@ -522,6 +522,17 @@ class GpuDCRTPolyMatrix:
         check_status(_ffi.lib().gpu_matrix_mul_scalar(out.raw, lhs.raw, s.raw), "gpu_matrix_mul_scalar")
         return out
 
+    def mul_scalar_intt(self, scalar) -> "GpuDCRTPolyMatrix":
+        """INTT(self o scalar) in one kernel (extension: the product rides in the inverse transform's load)."""
+        s = scalar.inner if hasattr(scalar, "inner") else scalar
+        lhs = self.ensure_eval()
+        s = s.ensure_eval()
+        out = GpuDCRTPolyMatrix(self.params, self.nrow, self.ncol, self.level, False)
+        if self.nrow == 0 or self.ncol == 0:
+            return out
+        check_status(_ffi.lib().gpupoly_matrix_mul_scalar_intt(out.raw, lhs.raw, s.raw), "gpupoly_matrix_mul_scalar_intt")
+        return out
+
     def __mul__(self, rhs):
         from .poly import GpuDCRTPoly
 

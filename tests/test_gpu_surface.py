@@ -189,3 +189,27 @@ def test_copy_to_context_and_sharded_preimages_two_contexts_one_device(gpu, orac
     assert [idx for idx, _ in outs] == [100 + i for i in range(6)]
     for (idx, xx), (_, p, td, a, t) in zip(outs, reqs):
         assert xx.params is p and a * xx == t
+
+
+@pytest.mark.parametrize("n,depth,bits,design", [(16384, 3, 24, "grouped"), (16384, 2, 24, "unsigned"), (16384, 2, 25, "grouped"),
+                                                 (16384, 2, 24, "whole"), (1024, 2, 24, "grouped"), (256, 2, 51, "grouped")])
+def test_mul_scalar_intt_fused(gpu, oracle, hip_env, n, depth, bits, design):
+    """gpupoly_matrix_mul_scalar_intt: INTT(x o w) with the product in the inverse transform's load (2^14-point
+    u32 kernels, signed and unsigned butterflies) and its two-call fallback elsewhere - bit-exact against
+    the CPU restatement, out-of-place and in place."""
+    from mxx_amd import _ffi
+
+    hip_env.set("MXX_HIP_NTT14", design)
+    p = make_params(gpu, oracle, n, depth, bits, 12 if bits <= 25 else 17)
+    moduli = p.moduli()
+    x = oracle.matrix_ntt(rand_matrix(oracle, 700, 2, 3, moduli, n), moduli)
+    w = oracle.matrix_ntt(rand_matrix(oracle, 701, 1, 1, moduli, n), moduli)
+    x[0, 0] = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(-1, 1)  # worst-case residues q-1
+    gx, gw = gpu.GpuDCRTPolyMatrix.from_rns(p, x, True), gpu.GpuDCRTPolyMatrix.from_rns(p, w, True)
+    want = oracle.matrix_ntt(oracle.pointwise("mul", x, w, moduli), moduli, inverse=True)
+    out = gx.mul_scalar_intt(gw)
+    assert not out.is_ntt and np.array_equal(out.to_rns(), want)
+    assert np.array_equal(gx.to_rns(), x)  # the operand is untouched
+    _ffi.check_status(_ffi.lib().gpupoly_matrix_mul_scalar_intt(gx.raw, gx.raw, gw.raw), "gpupoly_matrix_mul_scalar_intt")
+    gx.is_ntt = False
+    assert np.array_equal(gx.to_rns(), want)
