@@ -373,6 +373,12 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
         // MXX_HIP_MATMUL_PATH = reg | lds | dma forces a kernel family (tests cover all)
         const char force = ctx->env.matmul_path;
         const bool lds_ok = N >= 64 && (N % 64) == 0;
+        // MXX_HIP_MATMUL_PATH = reg | lds | dma | mfma forces a kernel family (tests cover all)
+        const bool want_mfma = force ? (force == 'm') : false;
+        if (want_mfma) {
+            const int rc = launch_matmul_mfma_u32(out, lhs, rhs);
+            if (rc >= 0) return rc;
+        }
         const bool want_dma = force ? (force == 'd') : (rows >= 32 && cols >= 16);
         if (want_dma) {
             const int rc = launch_matmul_dma_u32(out, lhs, rhs);

@@ -213,3 +213,40 @@ def test_mul_scalar_intt_fused(gpu, oracle, hip_env, n, depth, bits, design):
     _ffi.check_status(_ffi.lib().gpupoly_matrix_mul_scalar_intt(gx.raw, gx.raw, gw.raw), "gpupoly_matrix_mul_scalar_intt")
     gx.is_ntt = False
     assert np.array_equal(gx.to_rns(), want)
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 32), (64, 64, 64), (33, 12, 40), (40, 100, 70), (3, 16, 70), (64, 128, 32), (70, 5, 33)])
+@pytest.mark.parametrize("bits", [24, 22, 17])
+def test_matmul_mfma_kernel(gpu, oracle, hip_env, shape, bits):
+    """Matrix-core form of the R_q product (matmul_mfma.hip: centred residues as three balanced int8 digits,
+    v_mfma_i32_32x32x32_i8 into five significance planes, 64-bit recombination + Barrett): bit-exact against the
+    CPU restatement on full and ragged 32x32 tiles, inner dimensions that are not multiples of 32, and the
+    residues at the centring boundary (0, (q-1)/2, (q+1)/2, q-1)."""
+    r, k, c = shape
+    n = 128
+    moduli = oracle.gen_crt_basis(n, 2, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 8)
+    a = rand_matrix(oracle, 27, r, k, moduli, n)
+    b = rand_matrix(oracle, 28, k, c, moduli, n)
+    qs = np.asarray(moduli, dtype=np.uint64).reshape(-1, 1)
+    edge = np.concatenate([np.zeros_like(qs), (qs - 1) // 2, (qs + 1) // 2, qs - 1], axis=1)  # (L, 4)
+    a[0, :, :, :4] = edge
+    b[:, 0, :, :4] = edge[:, ::-1]
+    a[-1, :, :, 4:8] = (qs - 1)
+    b[:, -1, :, 4:8] = (qs - 1)
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    hip_env.set("MXX_HIP_MATMUL_PATH", "mfma")
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+
+
+def test_matmul_mfma_equals_valu_at_full_size(gpu, oracle, hip_env):
+    """64 x 64 x 64 at n = 2^14, L = 8 (BASELINE configs[2]): the matrix-core kernel and the VALU kernel agree."""
+    p = make_params(gpu, oracle, 16384, 8, 24, 12)
+    us = gpu.GpuDCRTPolyUniformSampler()
+    a = us.sample_uniform(p, 64, 64, gpu.DistType.FinRingDist())
+    b = us.sample_uniform(p, 64, 64, gpu.DistType.FinRingDist())
+    hip_env.set("MXX_HIP_MATMUL_PATH", "dma")
+    want = a * b
+    hip_env.set("MXX_HIP_MATMUL_PATH", "mfma")
+    assert a * b == want
