@@ -142,13 +142,17 @@ __global__ void __launch_bounds__(256)
             }
         }
     } else {
-        W acc[TR][TC][SV];
+        // 64-bit words: 128-bit lazy accumulators (a 51-bit prime leaves room for 2^26 products before the one
+        // reduction; lc.lazy_terms holds the window) instead of a Barrett reduction per term
+        u128_t acc[TR][TC][SV];
 #pragma unroll
         for (int r = 0; r < TR; ++r)
 #pragma unroll
             for (int c = 0; c < TC; ++c)
 #pragma unroll
                 for (int s = 0; s < SV; ++s) acc[r][c][s] = 0;
+        const uint32_t lazy = lc.lazy_terms;
+        uint32_t pending = 0;
         for (uint32_t k = 0; k < inner; ++k) {
             W av[TR][SV], bv[TC][SV];
 #pragma unroll
@@ -162,9 +166,17 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
                 for (int c = 0; c < TC; ++c)
 #pragma unroll
-                    for (int s = 0; s < SV; ++s)
-                        acc[r][c][s] =
-                            add_mod<W>(acc[r][c][s], mul_mod<W>(av[r][s], bv[c][s], q, lc.mu, lc.kbits), q);
+                    for (int s = 0; s < SV; ++s) acc[r][c][s] += static_cast<u128_t>(av[r][s]) * bv[c][s];
+            if (++pending == lazy) {
+                pending = 0;
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < TC; ++c)
+#pragma unroll
+                        for (int s = 0; s < SV; ++s)
+                            acc[r][c][s] = reduce_u128_sum(acc[r][c][s], q, lc.mu, lc.kbits, lc.mu64);
+            }
         }
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
@@ -172,8 +184,11 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
             for (int c = 0; c < TC; ++c) {
                 if (c0 + c >= cols) continue;
+                W o[SV];
+#pragma unroll
+                for (int s = 0; s < SV; ++s) o[s] = reduce_u128_sum(acc[r][c][s], q, lc.mu, lc.kbits, lc.mu64);
                 *reinterpret_cast<VT *>(C + ((static_cast<size_t>(r0 + r) * cols + (c0 + c)) * L + limb) * N + i) =
-                    *reinterpret_cast<const VT *>(acc[r][c]);
+                    *reinterpret_cast<const VT *>(o);
             }
         }
     }
@@ -362,12 +377,18 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
     const size_t rows = lhs->rows, cols = rhs->cols;
     const int N = ctx->N;
     if (ctx->wide) {
-        if (N >= 2) {
+        // small rings (BASELINE configs[4]: n = 256): a register tile per thread leaves most of the chip idle -
+        // (2x72)*(72x4) at L = 12 is 24 waves of 4x4x2 tiles.  Below ~2 waves per SIMD of tiled work, shrink the
+        // tile until the grid covers the chip (every output then re-reads its operands from L2, which is cheap there).
+        const uint64_t slots = static_cast<uint64_t>(N) * matrix_limbs(out);
+        const uint64_t want = 1024ull * 2 * 64;  // lanes for two waves on every SIMD
+        if (N >= 2 && slots / 2 * ((rows + 3) / 4) * ((cols + 3) / 4) >= want) {
             if (rows >= 4) return launch_matmul_cfg<uint64_t, 4, 4, 2>(out, lhs, rhs);
             if (rows >= 2) return launch_matmul_cfg<uint64_t, 2, 4, 2>(out, lhs, rhs);
             return launch_matmul_cfg<uint64_t, 1, 4, 2>(out, lhs, rhs);
         }
-        return launch_matmul_cfg<uint64_t, 1, 4, 1>(out, lhs, rhs);
+        if (slots * ((rows + 1) / 2) * ((cols + 1) / 2) >= want) return launch_matmul_cfg<uint64_t, 2, 2, 1>(out, lhs, rhs);
+        return launch_matmul_cfg<uint64_t, 1, 1, 1>(out, lhs, rhs);
     }
     {
         // MXX_HIP_MATMUL_PATH = reg | lds | dma forces a kernel family (tests cover all)

@@ -84,6 +84,18 @@ __device__ __forceinline__ uint32_t reduce_u64_sum(uint64_t acc, uint32_t q, uin
     return static_cast<uint32_t>(r);
 }
 
+// acc < 2^128 (lazily accumulated products of 64-bit residues), q < 2^62: result in [0,q).
+// acc = x1 2^64 + x0 = (x1 mod q) R + (x0 mod q) (mod q) with R = 2^64 mod q = -q mu64 (mod 2^64); the three
+// Barrett steps need their inputs below 2^(2k), which 64-bit words are once k >= 33.
+__device__ __forceinline__ uint64_t reduce_u128_sum(u128_t acc, uint64_t q, uint64_t mu, uint32_t k, uint64_t mu64) {
+    if (k < 33) return static_cast<uint64_t>(acc % q);  // small prime in a wide context: rare, keep it simple
+    const uint64_t x1 = static_cast<uint64_t>(acc >> 64), x0 = static_cast<uint64_t>(acc);
+    const uint64_t y1 = barrett_reduce(static_cast<u128_t>(x1), q, mu, k);
+    const uint64_t y0 = barrett_reduce(static_cast<u128_t>(x0), q, mu, k);
+    const uint64_t r64 = 0ull - q * mu64;
+    return barrett_reduce(static_cast<u128_t>(y1) * r64 + y0, q, mu, k);
+}
+
 // signed 64-bit integer -> residue in [0,q)
 template <typename W>
 __device__ __forceinline__ W signed_to_residue(int64_t v, W q) {

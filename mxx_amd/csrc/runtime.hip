@@ -395,7 +395,10 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
             u128h terms = ((((u128h)1) << 64) - q) / q2;
             lc.lazy_terms = terms > (1u << 20) ? (1u << 20) : static_cast<uint32_t>(terms);
         } else {
-            lc.lazy_terms = 1;
+            // 128-bit accumulators: (q - 1) + terms * (q - 1)^2 < 2^128 (q < 2^62: at least 15 terms)
+            u128h q2 = (u128h)(q - 1) * (q - 1);
+            u128h terms = (~(u128h)0 - q) / q2;
+            lc.lazy_terms = terms > (1u << 20) ? (1u << 20) : static_cast<uint32_t>(terms);
         }
     }
     ctx->crt_bits = crt_bits;

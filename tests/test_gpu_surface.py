@@ -250,3 +250,22 @@ def test_matmul_mfma_equals_valu_at_full_size(gpu, oracle, hip_env):
     want = a * b
     hip_env.set("MXX_HIP_MATMUL_PATH", "mfma")
     assert a * b == want
+
+
+@pytest.mark.parametrize("shape,n", [((2, 72, 4), 256), ((5, 9, 7), 256), ((1, 3, 1), 64), ((8, 40, 9), 4096), ((3, 70, 5), 16)])
+def test_matmul_u64_lazy_128bit_accumulators(gpu, oracle, shape, n):
+    """64-bit words (BASELINE configs[4]: 51-bit limbs): 128-bit lazy accumulators with one three-step Barrett
+    reduction per output, every register-tile configuration the launcher picks by occupancy, worst-case residues
+    q-1 in both operands, and a small prime riding in a wide context (the k < 33 branch of reduce_u128_sum)."""
+    r, k, c = shape
+    big = oracle.gen_crt_basis(n, 2, 51)
+    small = next(q for q in range(2 * n + 1, 1 << 20, 2 * n) if oracle.lib().orc_is_prime(q))
+    for moduli in (big, [big[0], small], oracle.gen_crt_basis(n, 1, 60)):
+        p = gpu.GpuDCRTPolyParams(n, moduli, 17)
+        assert p.ctx().word_bytes() == 8
+        a = rand_matrix(oracle, 31, r, k, moduli, n)
+        b = rand_matrix(oracle, 32, k, c, moduli, n)
+        top = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(-1, 1)
+        a[0], b[:, 0] = top, top
+        ga, gb = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True), gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+        assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
