@@ -41,7 +41,7 @@ template <typename W>
 __device__ __forceinline__ W mul_shoup(W x, W w, W wsh, W q) {
     W t = mulhi_w(x, wsh);
     W r = x * w - t * q;  // in [0, 2q)
-    return r >= q ? r - q : r;
+    return min(r, static_cast<W>(r - q));
 }
 
 // lazy variant: result in [0, 2q)

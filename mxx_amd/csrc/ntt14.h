@@ -23,10 +23,18 @@ constexpr uint32_t N = 1u << LOGN;
 constexpr uint32_t T = 512;                 // threads = 8 waves
 constexpr int R0 = 32;                      // elements per thread in the register pass (5 stages)
 constexpr uint32_t BLK = 512;               // sub-transform size after 5 stages
-constexpr uint32_t BLK_PAD = BLK + 64;      // +8 words per 64: strided set reads stay conflict-free
+constexpr uint32_t BLK_PAD = BLK + 64;      // +4 words per 32 (see pad64)
 constexpr uint32_t GROUP_WORDS = 8 * BLK_PAD;
 
-__device__ __forceinline__ uint32_t pad64(uint32_t pos) { return pos + ((pos >> 6) << 3); }
+// LDS position of element `pos` of a 512-point block: +4 words per 32.  The three access shapes of a block pass
+// are "lane + 64 m", "64 c + j + 8 m" (both one dword per lane) and "8 contiguous words per lane" (which the
+// compiler issues as two 128-bit accesses, with their own lane grouping: MI355X_MICROARCH.md, LDS table).  With the
+// round-1 padding (+8 per 64) the 128-bit reads ran at 3x and the 128-bit writes at 2x their conflict-free
+// cycles (SQ_LDS_BANK_CONFLICT = 15 % of SQ_LDS_IDX_ACTIVE); a bank simulation over paddings of the form
+// "a words per 2^b" (tools/lds_pad_search.py) finds +4 per 32 the best: dword shapes and 128-bit writes
+// conflict-free, 128-bit reads at 2x (an 8-word lane stride puts the 16 lanes of a 128-bit read group on even
+// 4-bank slots only; no padding in that family separates them without breaking the dword shapes).
+__device__ __forceinline__ uint32_t pad64(uint32_t pos) { return pos + ((pos >> 5) << 2); }
 
 // LDS ops of one wave execute in order; this only stops the compiler from moving them
 __device__ __forceinline__ void wave_sync() {
@@ -66,21 +74,22 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
         const uint32_t B = 8u * grp + wave;
         W v[8];
         {   // stages 5,6,7: sets {lane + 64 m}; twiddles are wave-uniform
+            const uint32_t base = pad64(lane);  // pad64(lane + 64 m) = pad64(lane) + 72 m
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[lane + 72 * m];
+            for (int m = 0; m < 8; ++m) v[m] = xb[base + 72 * m];
             ct_network_lazy<W, 3>(v, tw, B, 5, q, twoq);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) xb[lane + 72 * m] = v[m];
+            for (int m = 0; m < 8; ++m) xb[base + 72 * m] = v[m];
         }
         wave_sync();
         {   // stages 8,9,10: sets {64 c + j + 8 m}, c = lane/8, j = lane%8
             const uint32_t c = lane >> 3, j = lane & 7u;
-            const uint32_t base = 72 * c + j;
+            const uint32_t base = 72 * c + j;  // pad64(64 c + j + 8 m) = 72 c + j + 8 m + 4 (m >> 2)
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m];
+            for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m + 4 * (m >> 2)];
             ct_network_lazy<W, 3>(v, tw, B * 8u + c, 8, q, twoq);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) xb[base + 8 * m] = v[m];
+            for (int m = 0; m < 8; ++m) xb[base + 8 * m + 4 * (m >> 2)] = v[m];
         }
         wave_sync();
         {   // stages 11,12,13: 8 contiguous words per lane, then canonical form and out to HBM
@@ -220,7 +229,7 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
             const uint32_t c = lane >> 3, j = lane & 7u;
             const uint32_t base = 72 * c + j;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m];
+            for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m + 4 * (m >> 2)];
             if constexpr (SGN) {  // inputs <= 2 (which of them depends on the lane): keep <= 3
                 gs_network_signed<3, false>(v, tw, B * 8u + c, 8, q, lc);
                 gs_fold_signed<3, 2, 3>(v, q, muw);
@@ -229,12 +238,13 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
                 gs_fold<W, 3>(v, q, muw);
             }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) xb[base + 8 * m] = v[m];
+            for (int m = 0; m < 8; ++m) xb[base + 8 * m + 4 * (m >> 2)] = v[m];
         }
         wave_sync();
         {   // stages 7,6,5 (wave-uniform twiddles)
+            const uint32_t base = pad64(lane);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[lane + 72 * m];
+            for (int m = 0; m < 8; ++m) v[m] = xb[base + 72 * m];
             if constexpr (SGN) {  // inputs <= 3 (butterfly inputs reach 5); the register pass wants 1
                 gs_network_signed<3, false>(v, tw, B, 5, q, lc);
                 gs_fold_signed<3, 3, 1>(v, q, muw);
@@ -243,7 +253,7 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
                 gs_fold<W, 3>(v, q, muw);
             }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) xb[lane + 72 * m] = v[m];
+            for (int m = 0; m < 8; ++m) xb[base + 72 * m] = v[m];
         }
         __syncthreads();
         // transpose back: element `tid` of each of the group's 8 blocks

@@ -38,10 +38,20 @@ __device__ __forceinline__ W csub(W x, W m) {  // x in [0, 2m) -> [0, m)
     return min(x, static_cast<W>(x - m));
 }
 
+// -q as a value the optimiser cannot see through: "x + t * nq" then stays one multiply-add (v_mad_u64_u32, low
+// word) instead of being canonicalised back to a multiply and a subtract - same bits, one VALU instruction less
+// per lazy product (one register).
+template <typename W>
+__device__ __forceinline__ W opaque_neg(W q) {
+    W n = static_cast<W>(0) - q;
+    asm("" : "+v"(n));
+    return n;
+}
+
 // x < 2^bits(W) -> [0, 2q) with muw = floor(2^bits(W) / q)
 template <typename W>
 __device__ __forceinline__ W fold_2q(W x, W q, W muw) {
-    return x - mulhi_w(x, muw) * q;
+    return x + mulhi_w(x, muw) * opaque_neg<W>(q);
 }
 
 // ---- forward pass: stages [S_P, S_P + C), Cooley-Tukey, values grow by 2q per stage --------
@@ -90,13 +100,13 @@ __device__ __forceinline__ void gs_network_lazy(W (&v)[1 << C], const TwPair<W> 
             const W D = X + M - Y;
             if (LAST && k == 0) {
                 // last stage of the whole transform: fold N^-1 into both outputs
-                const W A = X + Y;
-                v[u] = A * static_cast<W>(lc.n_inv) - mulhi_w(A, static_cast<W>(lc.n_inv_sh)) * q;
-                v[u + half] = D * static_cast<W>(lc.inv_last_w) - mulhi_w(D, static_cast<W>(lc.inv_last_w_sh)) * q;
+                const W A = X + Y, nq = opaque_neg<W>(q);
+                v[u] = A * static_cast<W>(lc.n_inv) + mulhi_w(A, static_cast<W>(lc.n_inv_sh)) * nq;
+                v[u + half] = D * static_cast<W>(lc.inv_last_w) + mulhi_w(D, static_cast<W>(lc.inv_last_w_sh)) * nq;
             } else {
                 const TwPair<W> t = tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
                 v[u] = X + Y;
-                v[u + half] = D * t.w - mulhi_w(D, t.ws) * q;  // [0, 2q)
+                v[u + half] = D * t.w + mulhi_w(D, t.ws) * opaque_neg<W>(q);  // [0, 2q); multiply-add form
             }
         }
     }
@@ -125,7 +135,8 @@ __device__ __forceinline__ void gs_fold(W (&v)[1 << C], W q, W muw) {
 // although it wins in isolation (tools/bfly_forms.hip): the compiler splits the v_mad_u64_u32 into
 // v_mul_lo + v_sub once the product is subtracted, and instruction count matters more than operand count.
 __device__ __forceinline__ uint32_t smul_lazy(uint32_t x, uint32_t w, uint32_t ws, uint32_t q) {
-    return x * w - static_cast<uint32_t>(__mulhi(static_cast<int32_t>(x), static_cast<int32_t>(ws))) * q;
+    // x w + t (-q) (mod 2^32): v_mul_lo + v_mul_hi_i32 + v_mad_u64_u32 instead of two v_mul_lo and a v_sub
+    return x * w + static_cast<uint32_t>(__mulhi(static_cast<int32_t>(x), static_cast<int32_t>(ws))) * opaque_neg<uint32_t>(q);
 }
 // bound exponent (|x| < 2^e q) of element u after the stages that used bits 0..j, all inputs at e0
 __host__ __device__ constexpr int gs_exp_from(int e0, int u, int j) {
@@ -150,8 +161,8 @@ __device__ __forceinline__ void gs_network_signed(uint32_t (&v)[1 << C], const T
                 // last stage of the whole transform: |A|, |D| < 2^6 q; shift them to (0, 2^7 q) and
                 // finish with the unsigned Shoup product by N^-1 (resp. w N^-1): outputs in [0, 2q)
                 const uint32_t Ap = A + (q << 6), Dp = D + (q << 6);
-                v[u] = Ap * static_cast<uint32_t>(lc.n_inv) - __umulhi(Ap, static_cast<uint32_t>(lc.n_inv_sh)) * q;
-                v[u + half] = Dp * static_cast<uint32_t>(lc.inv_last_w) - __umulhi(Dp, static_cast<uint32_t>(lc.inv_last_w_sh)) * q;
+                v[u] = Ap * static_cast<uint32_t>(lc.n_inv) + __umulhi(Ap, static_cast<uint32_t>(lc.n_inv_sh)) * opaque_neg<uint32_t>(q);
+                v[u + half] = Dp * static_cast<uint32_t>(lc.inv_last_w) + __umulhi(Dp, static_cast<uint32_t>(lc.inv_last_w_sh)) * opaque_neg<uint32_t>(q);
             } else {
                 const TwPair<uint32_t> t = tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
                 v[u] = A;
@@ -167,7 +178,7 @@ __device__ __forceinline__ void gs_fold_signed(uint32_t (&v)[1 << C], uint32_t q
 #pragma unroll
     for (int u = 0; u < (1 << C); ++u)
         if (gs_exp_from(E0, u, C - 1) > KEEP)
-            v[u] = v[u] - static_cast<uint32_t>(__mulhi(static_cast<int32_t>(v[u]), static_cast<int32_t>(mu32))) * q;
+            v[u] = v[u] + static_cast<uint32_t>(__mulhi(static_cast<int32_t>(v[u]), static_cast<int32_t>(mu32))) * opaque_neg<uint32_t>(q);
 }
 
 template <typename W, int LOGN, int LOGR, bool INV>
