@@ -455,6 +455,9 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
     """The contract's timed region (K steps, barrier + synchronise on both sides, MAX over ranks), then
     `repeats` more repetitions of the same K steps for median / min."""
     mx = wl.mx
+    for i in range(steps):  # create every hipEvent before the timed region (creation on the host would be timed)
+        for j in range(wl.nmarks):
+            wl.mark(i, j)
     for i in range(warmup):
         wl.step(i, False)
     d.barrier_sync(mx.gpu_device_sync)

@@ -28,6 +28,19 @@ def test_crt_basis_matches_survey(key):
     assert O.gen_crt_basis(*key) == SURVEY_A1[key]
 
 
+def test_crt_basis_reference_held_datum():
+    """The one concrete value on this path that the reference itself holds: its GPU slot-transfer test builds
+    `GpuDCRTPolyParams::new(4, vec![131041, 131009], 1)` (src/slot_transfer/bgg_poly_encoding_gpu.rs:1501) - the
+    moduli OpenFHE's GenCRTBasis returns for DCRTPolyParams::default() = (n=4, depth 2, 17 bits),
+    src/poly/dcrt/params.rs:60-74.  The basis rule restated here (largest `bits`-bit prime = 1 mod 2n, then the
+    next smaller ones) reproduces it; every other entry of SURVEY_A1 is derived by the same rule and is NOT
+    pinned by the reference (parity stays unpinned at the byte level)."""
+    assert O.gen_crt_basis(4, 2, 17) == [131041, 131009]
+    from mxx_amd.params import DCRTPolyParams
+
+    assert DCRTPolyParams().to_crt()[0] == [131041, 131009]
+
+
 def test_modulus_bits_consistency():
     # in-tree consistency checks of the reference: modulus_bits == depth*bits
     # (src/poly/dcrt/params.rs:118-177)
