@@ -145,10 +145,10 @@ int gpu_poly_load_compact_bytes(GpuMatrix *poly, const uint8_t *payload, size_t 
                                 uint16_t max_coeff_bits);
 
 /* ---- MI355X extensions (not in the reference ABI; prefixed gpupoly_) ------- */
-/* S * G^-1(B) in one call (replaces the Rust-side loop src/matrix/gpu_dcrt_poly.rs:1414-1493): digits are
- * generated inside the forward transform's load and the product runs per column chunk; the digit matrix
- * of a chunk (<= 1 GiB) IS still written once and read once (a full fusion would need 8 x 16384
- * accumulators per workgroup).                                                     */
+/* S * G^-1(B) in one call (replaces the Rust-side loop src/matrix/gpu_dcrt_poly.rs:1414-1493, which re-reads S for
+ * every column chunk): digits are generated inside the forward transform's load for all columns at once when
+ * memory allows, then one product into `out`.  The EVAL-form digit matrix IS written once and read once (a full
+ * fusion would need 8 x 16384 accumulators per workgroup).                          */
 int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);
 /* out <- INTT(lhs o scalar_1x1): the point-wise product rides in the inverse transform's load (one HBM round
  * trip instead of two; replaces gpu_matrix_mul_scalar + gpu_matrix_intt_all).  out may be lhs.           */

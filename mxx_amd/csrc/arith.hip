@@ -512,9 +512,17 @@ extern "C" int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
     ABI_GUARD_END
 }
 
-// S * G^-1(B) in one ABI call (extension; the Rust wrapper loops column chunks,
-// src/matrix/gpu_dcrt_poly.rs:1414-1493).  Column chunks bound the transient digit matrix
-// to ~1 GiB; each chunk is decompose -> NTT -> product straight into the output columns.
+// S * G^-1(B) in one ABI call (extension; the Rust wrapper loops column chunks of width
+// MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH = 1, src/matrix/gpu_dcrt_poly.rs:1414-1493: slice, decompose, product,
+// copy_block per chunk, re-reading all of S for every chunk - 80.9 ms for (8x1024) * G^-1(64x64) at n = 2^14, L = 8).
+// Here: the digits are generated inside the forward transform's load (ntt14::fwd_digits_kernel; the coefficient-
+// domain digit matrix never exists) for ALL columns at once when memory allows - 288 GB of HBM hold the 34 GB digit
+// matrix of that shape - so S is read once and the product lands directly in `out` (29.7 ms: 20.4 transforms + 9.2
+// product); otherwise as few column chunks as fit.  What is NOT done: accumulating the product in the transform's
+// epilogue (8 x 16384 accumulators per workgroup), and overlapping the VALU-bound transforms with the HBM-bound
+// product on two streams - built and measured (blocks of source rows, C += S[:, block] D_block on a second,
+// higher-priority stream): 30.5-34 ms, never better than back to back, the transform grid fills every CU (4
+// workgroups of 36 KB LDS) and the product's workgroups only displace them (profiles/r02_notes.md).
 extern "C" int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs,
                                             uint32_t base_bits) {
     ABI_GUARD_BEGIN
@@ -522,7 +530,8 @@ extern "C" int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs
     if (out->ctx != lhs->ctx || out->ctx != rhs->ctx) return set_error("gpupoly_matrix_mul_decompose: context mismatch");
     if (out->level != lhs->level || out->level != rhs->level)
         return set_error("gpupoly_matrix_mul_decompose: level mismatch");
-    if (base_bits == 0) return set_error("gpupoly_matrix_mul_decompose: base_bits must be non-zero");
+    if (base_bits == 0 || base_bits >= 63) return set_error("gpupoly_matrix_mul_decompose: invalid base_bits");
+    if (out == lhs || out == rhs) return set_error("gpupoly_matrix_mul_decompose: output must not alias an input");
     GpuContext *ctx = out->ctx;
     const size_t L = matrix_limbs(out);
     const size_t k = static_cast<size_t>((ctx->crt_bits + base_bits - 1) / base_bits) * L;
@@ -531,19 +540,28 @@ extern "C" int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs
     if (lhs->format != GPU_POLY_FORMAT_EVAL) return set_error("gpupoly_matrix_mul_decompose requires Eval format");
     out->format = GPU_POLY_FORMAT_EVAL;
     if (matrix_polys(out) == 0) return 0;
+    if (ctx_activate(ctx)) return 1;
     const size_t poly_bytes = L * static_cast<size_t>(ctx->N) * ctx->word_bytes;
-    size_t chunk = std::max<size_t>(1, (size_t(1) << 30) / std::max<size_t>(1, rhs->rows * k * poly_bytes));
+    // digit-matrix budget: a third of what the device could give us now (cached blocks count as available)
+    size_t free_b = 0, total_b = 0, budget = size_t(8) << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max(budget, (free_b + ctx->cached_bytes) / 3);
+    else (void)hipGetLastError();
+    size_t chunk = std::max<size_t>(1, budget / std::max<size_t>(1, rhs->rows * k * poly_bytes));
     chunk = std::min(chunk, rhs->cols);
     for (size_t c0 = 0; c0 < rhs->cols; c0 += chunk) {
         const size_t cw = std::min(chunk, rhs->cols - c0);
+        const bool whole = cw == rhs->cols;
         GpuMatrix *slice = nullptr, *dec = nullptr, *prod = nullptr;
-        int rc = gpu_matrix_create(ctx, out->level, rhs->rows, cw, rhs->format, &slice);
-        if (!rc) rc = gpu_matrix_copy_block(slice, rhs, 0, 0, 0, c0, rhs->rows, cw);
+        int rc = 0;
+        if (!whole) {
+            rc = gpu_matrix_create(ctx, out->level, rhs->rows, cw, rhs->format, &slice);
+            if (!rc) rc = gpu_matrix_copy_block(slice, rhs, 0, 0, 0, c0, rhs->rows, cw);
+        }
         if (!rc) rc = gpu_matrix_create(ctx, out->level, rhs->rows * k, cw, GPU_POLY_FORMAT_EVAL, &dec);
-        if (!rc) rc = gpu_matrix_decompose_base(slice, base_bits, dec);
-        if (!rc) rc = gpu_matrix_create(ctx, out->level, lhs->rows, cw, GPU_POLY_FORMAT_EVAL, &prod);
-        if (!rc) rc = gpu_matrix_mul(prod, lhs, dec);
-        if (!rc) rc = gpu_matrix_copy_block(out, prod, 0, c0, 0, 0, lhs->rows, cw);
+        if (!rc) rc = gpu_matrix_decompose_base(whole ? rhs : slice, base_bits, dec);
+        if (!rc && !whole) rc = gpu_matrix_create(ctx, out->level, lhs->rows, cw, GPU_POLY_FORMAT_EVAL, &prod);
+        if (!rc) rc = gpu_matrix_mul(whole ? out : prod, lhs, dec);
+        if (!rc && !whole) rc = gpu_matrix_copy_block(out, prod, 0, c0, 0, 0, lhs->rows, cw);
         gpu_matrix_destroy(slice);
         gpu_matrix_destroy(dec);
         gpu_matrix_destroy(prod);

@@ -43,7 +43,6 @@ struct EnvSwitches {
     bool gsamp_simple = false;    // MXX_HIP_GSAMP=simple
     bool p1_simple = false;       // MXX_HIP_P1=simple
     int sampler_per_lane = 0;     // MXX_HIP_SAMPLER_PER_LANE (0 = sized for one resident round)
-    bool mul_decompose_fused = true;  // MXX_HIP_MUL_DECOMPOSE_FUSED=0: decompose-then-multiply in column chunks
     void load();
 };
 

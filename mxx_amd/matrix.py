@@ -20,6 +20,10 @@ from ._ffi import GPU_POLY_FORMAT_COEFF, GPU_POLY_FORMAT_EVAL, GpuRngSeed, check
 from .params import GpuDCRTPolyParams
 
 
+def mul_decompose_column_chunk_width_is_set() -> bool:
+    return bool(os.environ.get("MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"))
+
+
 def mul_decompose_column_chunk_width() -> int:
     """`MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH`, default 1 (src/env.rs of the reference)."""
     try:
@@ -634,6 +638,14 @@ class GpuDCRTPolyMatrix:
         ncol = other.ncol
         out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, ncol)
         if self.nrow == 0 or ncol == 0:
+            return out
+        if not mul_decompose_column_chunk_width_is_set():
+            # one ABI call: digits generated inside the forward transform, transforms and product overlapped on two
+            # streams, S read once (gpupoly_matrix_mul_decompose).  The reference's column-chunk loop below (chunk
+            # width 1 by default, re-reading S per chunk) runs only when its env switch is set explicitly.
+            lhs = self.ensure_eval()
+            st = _ffi.lib().gpupoly_matrix_mul_decompose(out.raw, lhs.raw, other.raw, self.params.base_bits())
+            check_status(st, "gpupoly_matrix_mul_decompose")
             return out
         width = min(mul_decompose_column_chunk_width(), ncol)
         for c0 in range(0, ncol, width):

@@ -1,4 +1,6 @@
 """GPU parity for the compact wire format and staging bytes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -97,7 +99,12 @@ def test_mul_decompose_extension_matches_chunked(gpu, oracle):
     k = p.modulus_digits()
     S = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 103, 2, 3 * k, moduli, n), True)
     B = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 104, 3, 5, moduli, n), True)
-    want = S.mul_decompose(B)
+    os.environ["MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"] = "2"  # the reference's column-chunk loop
+    try:
+        want = S.mul_decompose(B)
+    finally:
+        del os.environ["MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"]
+    assert S.mul_decompose(B) == want  # default: the one-call extension
     out = gpu.GpuDCRTPolyMatrix.new_empty(p, 2, 5)
     _ffi.check_status(_ffi.lib().gpupoly_matrix_mul_decompose(out.raw, S.raw, B.raw, base), "gpupoly_matrix_mul_decompose")
     assert out == want

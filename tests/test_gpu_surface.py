@@ -269,3 +269,25 @@ def test_matmul_u64_lazy_128bit_accumulators(gpu, oracle, shape, n):
         a[0], b[:, 0] = top, top
         ga, gb = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True), gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
         assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+
+
+@pytest.mark.parametrize("rows_s,rows_b,cols_b,eval_b", [(2, 2, 3, True), (8, 5, 4, False)])
+def test_mul_decompose_one_call_at_2_14(gpu, oracle, rows_s, rows_b, cols_b, eval_b):
+    """gpupoly_matrix_mul_decompose at n = 2^14 (digits generated inside the forward transform, all columns at once,
+    product straight into the output; what GpuDCRTPolyMatrix.mul_decompose calls by default): bit-exact against the
+    CPU restatement's decompose + product, for COEFF and EVAL operands."""
+    n, base = 16384, 12
+    p = make_params(gpu, oracle, n, 2, 24, base)
+    moduli = p.moduli()
+    k = p.modulus_digits()
+    S = oracle.matrix_ntt(rand_matrix(oracle, 801, rows_s, rows_b * k, moduli, n), moduli)
+    Bc = rand_matrix(oracle, 802, rows_b, cols_b, moduli, n)
+    want = oracle.matmul(S, oracle.matrix_ntt(oracle.decompose(Bc, moduli, base), moduli), moduli)
+    gs = gpu.GpuDCRTPolyMatrix.from_rns(p, S, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, Bc, False)
+    if eval_b:
+        gb.ntt_all_in_place()
+    keep = gb.to_rns().copy()
+    got = gs.mul_decompose(gb)
+    assert np.array_equal(got.to_rns(), want)
+    assert np.array_equal(gb.to_rns(), keep) and gb.is_ntt == eval_b  # the operand is untouched

@@ -28,3 +28,7 @@ if which == "dec":
     print("mul_decompose (8 x %d) * G^-1(64x64), chunk 1: %.2f ms" % (64 * k, timed(ctx, lambda: S.mul_decompose(M), 1)))
     os.environ["MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"] = "64"
     print("mul_decompose chunk 64: %.2f ms" % timed(ctx, lambda: S.mul_decompose(M), 2))
+    out2 = mx.GpuDCRTPolyMatrix(p, 8, 64, 7, True)
+    print("gpupoly_matrix_mul_decompose (C ABI, one call): %.2f ms" % timed(ctx, lambda: _ffi.check_status(_ffi.lib().gpupoly_matrix_mul_decompose(out2.raw, S.raw, M.raw, 12), "mul_decompose"), 2))
+    D = M.decompose()
+    print("product (8x%d)*(%dx64) alone: %.2f ms" % (64 * k, 64 * k, timed(ctx, lambda: S * D, 2)))
