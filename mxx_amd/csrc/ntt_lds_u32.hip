@@ -1,6 +1,7 @@
 // ntt_lds_u32.hip — instantiations of the lazy LDS NTT for 32-bit residue words.
 #include "ntt14.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -23,9 +24,23 @@ int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff,
     if (ctx->logN != 14 || !ctx->lazy_ok || env.ntt14 == 1 || env.ntt_path > 1 || !env.decompose_fused ||
         out_vectors > 0x7fffffffull || k >> 32)
         return -1;
-    hipLaunchKernelGGL(ntt14::fwd_digits_kernel<W>, dim3(static_cast<unsigned>(out_vectors)), dim3(ntt14::T),
-                       ntt14::lds_bytes(sizeof(W)), ctx->stream, out, coeff, static_cast<const TwPair<W> *>(ctx->d_tw2_fwd),
-                       ctx->d_limbs, L, src_cols, towers, dpt, base_bits, static_cast<uint32_t>(k));
+    if (k == 0 || src_cols == 0 || out_vectors % (k * src_cols * L) != 0) return -1;
+    const size_t src_rows = out_vectors / (k * src_cols * L);
+    if (src_rows > 65535 || k > 65535 || static_cast<uint64_t>(src_cols) * L > 0x7fffffffull) return -1;
+    // can a digit reach an output modulus?  (digits are below 2^min(base_bits, bits of the widest limb))
+    const uint32_t digit_bits = std::min<uint32_t>(base_bits, ctx->crt_bits);
+    uint64_t min_q = ~0ull;
+    for (uint32_t l = 0; l < L; ++l) min_q = std::min<uint64_t>(min_q, ctx->moduli[l]);
+    const bool reduce = digit_bits >= 63 || ((1ull << digit_bits) - 1) >= min_q;
+    const dim3 grid(8u * L * ((src_cols + 7u) / 8u), static_cast<unsigned>(k), static_cast<unsigned>(src_rows));
+    if (reduce)
+        hipLaunchKernelGGL((ntt14::fwd_digits_kernel<W, true>), grid, dim3(ntt14::T), ntt14::lds_bytes(sizeof(W)), ctx->stream, out,
+                           coeff, static_cast<const TwPair<W> *>(ctx->d_tw2_fwd), ctx->d_limbs, L, src_cols, towers, dpt,
+                           base_bits, static_cast<uint32_t>(k));
+    else
+        hipLaunchKernelGGL((ntt14::fwd_digits_kernel<W, false>), grid, dim3(ntt14::T), ntt14::lds_bytes(sizeof(W)), ctx->stream, out,
+                           coeff, static_cast<const TwPair<W> *>(ctx->d_tw2_fwd), ctx->d_limbs, L, src_cols, towers, dpt,
+                           base_bits, static_cast<uint32_t>(k));
     HIP_TRY(hipGetLastError());
     return 0;
 }
