@@ -20,6 +20,17 @@
 // Operand traffic: A and B panels are each read by two workgroups (tools/mfma_probe.hip: 64-byte runs
 // with one re-reader on the same XCD stream at ~6.4 TB/s delivered); the tile order keeps the four
 // tiles that share panels next to each other on one XCD.
+// A pipelined second form was built and measured as well (persistent workgroups of 8 waves x 2 slots, K in chunks of
+// 16 with v_mfma_i32_32x32x16_i8, two chunks = 131 KB of operand loads in flight across chunk and tile boundaries,
+// planes 0/2/4 accumulated straight into three running words inside the matrix core, branch-free loads so that the
+// compiler's wait counts leave the younger chunk in flight, epilogue constants and the item list precomputed into
+// LDS: 250 VGPRs, no spills, bit-exact): 3.49 ms - the same as this form.  Its phases: loads + conversion alone
+// 2.36 ms, everything except the loads 1.33 ms, matrix cores + recombination + stores 0.91 ms; 0.37 ms per limb for
+// L = 7, 9, 10 against 0.44 for L = 8 (the 512 KB polynomial stride aliases in L2).  With two chunks always in flight
+// the operand stream still delivers only ~3.7-4.1 TB/s (8.6 GB per product), i.e. the transposing access shape - 64-byte
+// runs at a polynomial stride, 1024 of them per chunk per CU - is throughput-bound below what the VALU kernel's 256-byte
+// rows reach, and deeper prefetch does not change it (profiles/r02_notes.md).  It was removed again; this simpler
+// form stays as the measured prototype.
 // Limits of this form: rows, cols >= 32 pays; inner <= 128 (the int32 planes and their 32-bit pairwise
 // recombination are sized for it); every modulus < 16 711 424 (centred residues must keep |d2| < 128).
 // Otherwise launch_matmul falls back to the VALU kernels (matmul_dma.hip, arith.hip).

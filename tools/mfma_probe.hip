@@ -28,6 +28,68 @@ __global__ void mfma_layout_kernel(const int8_t *a, const int8_t *b, int *d) {
     }
 }
 
+__global__ void mfma16_layout_kernel(const int8_t *a, const int8_t *b, int *d) {
+    // assumed: lane l (r = l & 31, h = l >> 5) holds A[r][8h + j] and B[8h + j][r], j = 0..7 (k = 16 per instruction)
+    const int l = threadIdx.x, r = l & 31, h = l >> 5;
+    union { long v; int8_t e[8]; } fa, fb;
+    for (int j = 0; j < 8; ++j) {
+        fa.e[j] = a[r * 16 + 8 * h + j];
+        fb.e[j] = b[(8 * h + j) * 32 + r];
+    }
+    v16i acc = {0};
+    acc = __builtin_amdgcn_mfma_i32_32x32x16_i8(fa.v, fb.v, acc, 0, 0, 0);
+    for (int reg = 0; reg < 16; ++reg) d[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r] = acc[reg];
+}
+
+__global__ void mfma_rate_kernel(int *out, int iters) {
+    // issue rate of the two i8 forms, one wave per SIMD: 4 independent accumulators each
+    v16i acc[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = threadIdx.x + i;
+    v4i a32 = {1, 2, 3, 4}, b32 = {5, 6, 7, 8};
+    long a16 = 0x0102030405060708l, b16 = 0x0807060504030201l;
+    long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it)
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a32, b32, acc[i], 0, 0, 0);
+    long t1 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it)
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a16, b16, acc[i], 0, 0, 0);
+    long t2 = __builtin_amdgcn_s_memtime();
+    int r = 0;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) r += acc[i][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[100000] = (int)(t1 - t0); out[100001] = (int)(t2 - t1); }
+}
+
+static void check_layout16() {
+    std::vector<int8_t> a(32 * 16), b(16 * 32);
+    for (int i = 0; i < 32 * 16; ++i) {
+        a[i] = static_cast<int8_t>((i * 37 + 11) % 251 - 125);
+        b[i] = static_cast<int8_t>((i * 91 + 5) % 241 - 120);
+    }
+    int8_t *da, *db;
+    int *dd;
+    (void)hipMalloc(&da, 512); (void)hipMalloc(&db, 512); (void)hipMalloc(&dd, 4096 * 128);
+    (void)hipMemcpy(da, a.data(), 512, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b.data(), 512, hipMemcpyHostToDevice);
+    mfma16_layout_kernel<<<1, 64>>>(da, db, dd);
+    std::vector<int> d(1024);
+    (void)hipMemcpy(d.data(), dd, 4096, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            int want = 0;
+            for (int k = 0; k < 16; ++k) want += int(a[i * 16 + k]) * int(b[k * 32 + j]);
+            if (want != d[i * 32 + j]) ++bad;
+        }
+    printf("mfma_i32_32x32x16_i8 lane map A[l&31][8(l>>5)+j], B[8(l>>5)+j][l&31]: %s (%d mismatches)\n", bad ? "WRONG" : "ok", bad);
+    const int iters = 2000;
+    mfma_rate_kernel<<<1, 64>>>(dd, iters);
+    std::vector<int> t(2);
+    (void)hipMemcpy(t.data(), dd + 100000, 8, hipMemcpyDeviceToHost);
+    printf("s_memtime ticks per MFMA, one wave: 32x32x32_i8 %.1f, 32x32x16_i8 %.1f\n", t[0] / (4.0 * iters), t[1] / (4.0 * iters));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dd);
+}
+
 static void check_layout() {
     std::vector<int8_t> a(32 * 32), b(32 * 32);
     for (int i = 0; i < 32 * 32; ++i) {
@@ -105,8 +167,10 @@ static void run_stream(const uint32_t *data, uint32_t *out, uint32_t P, uint32_t
            S, S * 4, blocks, reread, best, bytes / best / 1e9, bytes * reread / best / 1e9);
 }
 
-int main() {
+int main(int argc, char **argv) {
     check_layout();
+    check_layout16();
+    if (argc > 1) return 0;  // layout / rate checks only
     const uint32_t P = 8192, L = 8, N = 16384;  // A and B of the 64^3 product at L = 8: 4.3 GB
     uint32_t *data, *out;
     const size_t words = size_t(P) * L * N;
