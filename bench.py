@@ -321,6 +321,11 @@ class MatMul(Workload):
         if col is not None:
             one = self.a * col
             assert one == self.out.slice_columns(0, 1), "product column differs between kernel paths"
+        if self.gather is not None and self.c_local:  # the gathered matrix holds this rank's block where it belongs
+            from mxx_amd.parallel import shard_range
+
+            sr = shard_range(self.shape[2], self.d.world, self.d.rank)
+            assert self.full.slice_columns(sr.start, sr.stop) == self.out, "gathered product block differs"
 
 
 class M2A(MatMul):

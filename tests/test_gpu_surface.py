@@ -291,3 +291,19 @@ def test_mul_decompose_one_call_at_2_14(gpu, oracle, rows_s, rows_b, cols_b, eva
     got = gs.mul_decompose(gb)
     assert np.array_equal(got.to_rns(), want)
     assert np.array_equal(gb.to_rns(), keep) and gb.is_ntt == eval_b  # the operand is untouched
+
+
+@pytest.mark.parametrize("path", ["reg", "lds", "dma"])
+def test_matmul_lazy_window_worst_case_both_operands(gpu, oracle, hip_env, path):
+    """31-bit primes, every residue of BOTH operands q-1, inner dimension far beyond the lazy window: the 64-bit
+    accumulators carry a folded residue into every window of products (runtime.hip: lazy_terms = (2^64 - q) / (q-1)^2;
+    the round-1 formula (2^64 - 1) / (q-1)^2 ignored the carried residue)."""
+    n, r, k, c = 128, 32, 96, 16
+    moduli = oracle.gen_crt_basis(n, 2, 31)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 8)
+    top = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1)
+    a = np.broadcast_to(top, (r, k, len(moduli), n)).copy()
+    b = np.broadcast_to(top, (k, c, len(moduli), n)).copy()
+    hip_env.set("MXX_HIP_MATMUL_PATH", path)
+    got = (gpu.GpuDCRTPolyMatrix.from_rns(p, a, True) * gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)).to_rns()
+    assert np.array_equal(got, oracle.matmul(a, b, moduli))
