@@ -29,28 +29,84 @@ struct SerdeConsts {
     uint64_t half[kMaxWords];     // floor(Q/2)
 };
 
-// residues of coefficient (poly, i) -> |x| words (little-endian), sign; returns bit width of |x|
-template <typename W>
+// residues of coefficient (poly, i) -> |x| words (little-endian), sign; returns bit width of |x|.
+// ML bounds the limb count at compile time (8, 16 or 64) so that the mixed-radix digits and the words of x stay in
+// registers for the sizes that matter (the unbounded form kept two 64-entry arrays in scratch memory).
+// Fast path: the matrices that are serialised most - preimages, trapdoors, Gaussian-sized keys - hold SMALL integers:
+// if every limb's residue is the residue of the centred limb-0 value c (|c| <= q_0 / 2), then x = c, by uniqueness of
+// the CRT representative in (-Q/2, Q/2]; that is an O(L) comparison instead of the O(L^2) Garner recurrence.
+// General path: Garner's products go through Barrett (mu of every limb from the context) instead of a 128-bit `%`.
+template <typename W, int ML>
 __device__ __forceinline__ uint32_t reconstruct_centered(const W *__restrict__ src, size_t poly, uint32_t i, uint32_t N,
                                                          const SerdeConsts &sc, const uint64_t *__restrict__ garner,
-                                                         size_t garner_stride, uint64_t *x, bool &negative) {
+                                                         size_t garner_stride, const LimbConst *__restrict__ limbs,
+                                                         uint64_t *x, bool &negative) {
     const int L = sc.limbs, WC = sc.words;
-    uint64_t v[GPUPOLY_MAX_LIMBS];
-    // Garner: v_k = (r_k - (v_0 + v_1 q_0 + ...)) / (q_0 .. q_{k-1})  mod q_k, computed incrementally
-    for (int k = 0; k < L; ++k) {
-        const uint64_t qk = sc.q[k];
-        uint64_t t = static_cast<uint64_t>(src[(poly * L + k) * N + i]);
-        for (int j = 0; j < k; ++j) {
-            const uint64_t vj = v[j] % qk;
-            const uint64_t d = t >= vj ? t - vj : t + qk - vj;
-            t = static_cast<uint64_t>((static_cast<u128_t>(d) * garner[k * garner_stride + j]) % qk);
+    uint64_t res[ML];
+    if constexpr (ML <= 16) {
+#pragma unroll
+        for (int k = 0; k < ML; ++k)
+            if (k < L) res[k] = static_cast<uint64_t>(src[(poly * L + k) * N + i]);
+    } else {
+        for (int k = 0; k < L; ++k) res[k] = static_cast<uint64_t>(src[(poly * L + k) * N + i]);
+    }
+    {
+        const uint64_t q0 = sc.q[0];
+        const bool neg0 = res[0] > (q0 >> 1);
+        const uint64_t mag = neg0 ? q0 - res[0] : res[0];  // |c|
+        bool small = true;
+        auto same = [&](int k) {
+            const uint64_t qk = sc.q[k];
+            return mag < qk && res[k] == (neg0 ? qk - mag : mag);
+        };
+        if constexpr (ML <= 16) {
+#pragma unroll
+            for (int k = 1; k < ML; ++k)
+                if (k < L) small = small && same(k);
+        } else {
+            for (int k = 1; k < L; ++k) small = small && same(k);
         }
-        v[k] = t;
+        if (small) {
+            for (int w = 0; w < WC; ++w) x[w] = 0;
+            x[0] = mag;
+            negative = neg0 && mag != 0;
+            return mag ? 64u - static_cast<uint32_t>(__clzll(mag)) : 0u;
+        }
+    }
+    uint64_t v[ML];
+    // Garner: v_k = (r_k - (v_0 + v_1 q_0 + ...)) / (q_0 .. q_{k-1})  mod q_k, computed incrementally
+    auto garner_step = [&](int k, int j, uint64_t t, uint64_t qk, uint64_t mu, uint32_t kb) {
+        uint64_t vj = v[j];
+        if (vj >= qk) vj %= qk;  // only when an earlier modulus is wider than this one
+        const uint64_t d = t >= vj ? t - vj : t + qk - vj;
+        const uint64_t g = garner[k * garner_stride + j];
+        if constexpr (sizeof(W) == 4) return static_cast<uint64_t>(barrett_reduce(d * g, static_cast<uint32_t>(qk), mu, kb));
+        else return barrett_reduce(static_cast<u128_t>(d) * g, qk, mu, kb);
+    };
+    if constexpr (ML <= 16) {  // fully unrolled, guarded: everything stays in registers
+#pragma unroll
+        for (int k = 0; k < ML; ++k)
+            if (k < L) {
+                const uint64_t qk = sc.q[k], mu = limbs[k].mu;
+                const uint32_t kb = limbs[k].kbits;
+                uint64_t t = res[k];
+#pragma unroll
+                for (int j = 0; j < ML; ++j)
+                    if (j < k) t = garner_step(k, j, t, qk, mu, kb);
+                v[k] = t;
+            }
+    } else {
+        for (int k = 0; k < L; ++k) {
+            const uint64_t qk = sc.q[k], mu = limbs[k].mu;
+            const uint32_t kb = limbs[k].kbits;
+            uint64_t t = res[k];
+            for (int j = 0; j < k; ++j) t = garner_step(k, j, t, qk, mu, kb);
+            v[k] = t;
+        }
     }
     // Horner: x = (..(v_{L-1} q_{L-2} + v_{L-2}) q_{L-3} + ..) q_0 + v_0
     for (int w = 0; w < WC; ++w) x[w] = 0;
-    x[0] = v[L - 1];
-    for (int k = L - 2; k >= 0; --k) {
+    auto horner_step = [&](int k) {
         const uint64_t m = sc.q[k];
         u128_t carry = v[k];
         for (int w = 0; w < WC; ++w) {
@@ -58,6 +114,16 @@ __device__ __forceinline__ uint32_t reconstruct_centered(const W *__restrict__ s
             x[w] = static_cast<uint64_t>(p);
             carry = p >> 64;
         }
+    };
+    if constexpr (ML <= 16) {
+#pragma unroll
+        for (int k = ML - 1; k >= 0; --k) {
+            if (k == L - 1) x[0] = v[k];
+            else if (k < L - 1) horner_step(k);
+        }
+    } else {
+        x[0] = v[L - 1];
+        for (int k = L - 2; k >= 0; --k) horner_step(k);
     }
     // centre: negative iff x > floor(Q/2)
     int cmp = 0;
@@ -82,34 +148,34 @@ __device__ __forceinline__ uint32_t reconstruct_centered(const W *__restrict__ s
     return 0;
 }
 
-template <typename W>
+template <typename W, int ML>
 __global__ void compact_maxbits_kernel(const W *__restrict__ src, size_t polys, uint32_t N, SerdeConsts sc,
                                        const uint64_t *__restrict__ garner, size_t garner_stride,
-                                       unsigned int *__restrict__ max_bits) {
+                                       const LimbConst *__restrict__ limbs, unsigned int *__restrict__ max_bits) {
     const size_t idx = item_index();
     unsigned int bits = 0;
     if (idx < polys * N) {
-        uint64_t x[kMaxWords];
+        uint64_t x[ML];
         bool neg;
-        bits = reconstruct_centered<W>(src, idx / N, static_cast<uint32_t>(idx % N), N, sc, garner, garner_stride, x, neg);
+        bits = reconstruct_centered<W, ML>(src, idx / N, static_cast<uint32_t>(idx % N), N, sc, garner, garner_stride, limbs, x, neg);
     }
     // wave-level max, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) bits = max(bits, __shfl_down(bits, off));
     if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_bits, bits);
 }
 
-template <typename W>
+template <typename W, int ML>
 __global__ void compact_pack_kernel(const W *__restrict__ src, size_t polys, uint32_t N, SerdeConsts sc,
-                                    const uint64_t *__restrict__ garner, size_t garner_stride, uint32_t width,
-                                    uint32_t *__restrict__ payload_words) {
+                                    const uint64_t *__restrict__ garner, size_t garner_stride,
+                                    const LimbConst *__restrict__ limbs, uint32_t width, uint32_t *__restrict__ payload_words) {
     const size_t idx = item_index();
     if (idx >= polys * N) return;
-    uint64_t x[kMaxWords + 1];
+    uint64_t x[ML + 1];  // words of |x| (at most one per limb) + one for the sign bit / the shifted read below
     bool neg;
-    reconstruct_centered<W>(src, idx / N, static_cast<uint32_t>(idx % N), N, sc, garner, garner_stride, x, neg);
+    reconstruct_centered<W, ML>(src, idx / N, static_cast<uint32_t>(idx % N), N, sc, garner, garner_stride, limbs, x, neg);
     // set the sign bit at position width-1
     const uint32_t sb = width - 1;
-    for (int w = sc.words; w <= kMaxWords; ++w) x[w] = 0;
+    for (int w = sc.words; w <= ML; ++w) x[w] = 0;
     if (neg) x[sb >> 6] |= 1ull << (sb & 63);
     // OR the `width` bits into the stream at bit offset idx*width, 32 bits at a time
     const size_t base = idx * static_cast<size_t>(width);
@@ -127,9 +193,21 @@ __global__ void compact_pack_kernel(const W *__restrict__ src, size_t polys, uin
     }
 }
 
+// 32 bits of the payload starting at bit `bit` (little-endian bit stream); the payload is padded by 8 bytes
+__device__ __forceinline__ uint32_t payload_bits32(const uint8_t *__restrict__ payload, size_t bit) {
+    const size_t byte = bit >> 3;
+    uint64_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) v |= static_cast<uint64_t>(payload[byte + b]) << (8 * b);
+    return static_cast<uint32_t>(v >> (bit & 7));
+}
+
+// |x| arrives as `mag_bits` bits; every limb reduces it 32 bits at a time, most significant first:
+// r <- (r 2^32 + word) mod q, one multiply-high by floor(2^64 / q) per step for word-sized moduli (the first form
+// reduced a 128-bit value with `%` for every byte of every limb)
 template <typename W>
 __global__ void compact_unpack_kernel(W *__restrict__ dst, const uint8_t *__restrict__ payload, size_t polys,
-                                      uint32_t N, SerdeConsts sc, uint32_t width) {
+                                      uint32_t N, SerdeConsts sc, const LimbConst *__restrict__ limbs, uint32_t width) {
     const size_t idx = item_index();
     if (idx >= polys * N) return;
     const size_t poly = idx / N;
@@ -143,22 +221,24 @@ __global__ void compact_unpack_kernel(W *__restrict__ dst, const uint8_t *__rest
     const uint32_t mag_bits = width - 1;
     const size_t sbit = base + mag_bits;
     const bool neg = (payload[sbit >> 3] >> (sbit & 7)) & 1u;
+    const uint32_t words = (mag_bits + 31) / 32, top_bits = mag_bits - (words - 1) * 32;  // top_bits in 1..32 (words >= 1)
     for (int l = 0; l < L; ++l) {
-        const uint64_t q = sc.q[l];
+        const LimbConst lc = limbs[l];
+        const uint64_t q = lc.q;
         uint64_t r = 0;
-        // most-significant bits first, a byte-aligned chunk at a time
-        uint32_t remaining = mag_bits;
-        while (remaining) {
-            const size_t top = base + remaining;            // one past the highest unread bit
-            uint32_t take = static_cast<uint32_t>(top & 7);  // bits of this chunk inside the top byte
-            if (take == 0) take = 8;
-            take = min(take, remaining);
-            const size_t lo = top - take;
-            const uint32_t byte = payload[lo >> 3];
-            const uint32_t chunk = (byte >> (lo & 7)) & ((1u << take) - 1);
-            r = static_cast<uint64_t>(((static_cast<u128_t>(r) << take) + chunk) % q);
-            remaining -= take;
+        for (uint32_t j = words; j-- > 0;) {
+            uint32_t w = payload_bits32(payload, base + 32u * j);
+            if (j == words - 1 && top_bits < 32) w &= (1u << top_bits) - 1u;
+            if constexpr (sizeof(W) == 4) {
+                const uint64_t x = (r << 32) | w;  // r < q < 2^31
+                r = x - __umul64hi(x, lc.mu64) * q;
+                if (r >= q) r -= q;
+            } else {
+                const u128_t x = (static_cast<u128_t>(r) << 32) | w;
+                r = lc.kbits >= 32 ? barrett_reduce(x, q, lc.mu, lc.kbits) : static_cast<uint64_t>(x % q);
+            }
         }
+        if (mag_bits == 0) r = 0;
         if (neg && r) r = q - r;
         dst[(poly * L + l) * N + i] = static_cast<W>(r);
     }
@@ -222,14 +302,18 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     if (max_block.alloc(sizeof(unsigned int))) return 1;
     void *const d_max = max_block.ptr;
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned int), ctx->stream));
+#define SERDE_LAUNCH(KERNEL, WT, ...)                                                                                  \
+    do {                                                                                                               \
+        if (sc.limbs <= 8) hipLaunchKernelGGL((KERNEL<WT, 8>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);         \
+        else if (sc.limbs <= 16) hipLaunchKernelGGL((KERNEL<WT, 16>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((KERNEL<WT, 64>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);                      \
+    } while (0)
     if (ctx->wide)
-        hipLaunchKernelGGL(compact_maxbits_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
-                           static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride,
-                           static_cast<unsigned int *>(d_max));
+        SERDE_LAUNCH(compact_maxbits_kernel, uint64_t, static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner,
+                     gstride, ctx->d_limbs, static_cast<unsigned int *>(d_max));
     else
-        hipLaunchKernelGGL(compact_maxbits_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
-                           static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride,
-                           static_cast<unsigned int *>(d_max));
+        SERDE_LAUNCH(compact_maxbits_kernel, uint32_t, static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner,
+                     gstride, ctx->d_limbs, static_cast<unsigned int *>(d_max));
     HIP_TRY(hipGetLastError());
     unsigned int h_max = 0;
     HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream));
@@ -248,13 +332,12 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
         void *const d_payload = payload_block.ptr;
         HIP_TRY(hipMemsetAsync(d_payload, 0, padded, ctx->stream));
         if (ctx->wide)
-            hipLaunchKernelGGL(compact_pack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
-                               static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride, width,
-                               static_cast<uint32_t *>(d_payload));
+            SERDE_LAUNCH(compact_pack_kernel, uint64_t, static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner,
+                         gstride, ctx->d_limbs, width, static_cast<uint32_t *>(d_payload));
         else
-            hipLaunchKernelGGL(compact_pack_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
-                               static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner, gstride, width,
-                               static_cast<uint32_t *>(d_payload));
+            SERDE_LAUNCH(compact_pack_kernel, uint32_t, static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner,
+                         gstride, ctx->d_limbs, width, static_cast<uint32_t *>(d_payload));
+#undef SERDE_LAUNCH
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(payload_out, d_payload, payload_len, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -288,7 +371,8 @@ extern "C" int gpu_matrix_load_compact_bytes(GpuMatrix *mat, const uint8_t *payl
     if (build_consts(mat, sc)) return 1;
     CtxBlock payload_block(ctx);
     if (payload_len) {
-        if (payload_block.alloc(payload_len)) return 1;
+        if (payload_block.alloc(payload_len + 8)) return 1;  // payload_bits32 reads up to 4 bytes past a coefficient
+        HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(payload_block.ptr) + payload_len, 0, 8, ctx->stream));
         HIP_TRY(hipMemcpyAsync(payload_block.ptr, payload, payload_len, hipMemcpyHostToDevice, ctx->stream));
     }
     void *const d_payload = payload_block.ptr;
@@ -296,11 +380,11 @@ extern "C" int gpu_matrix_load_compact_bytes(GpuMatrix *mat, const uint8_t *payl
     if (ctx->wide)
         hipLaunchKernelGGL(compact_unpack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(mat->data), static_cast<const uint8_t *>(d_payload), polys, N, sc,
-                           static_cast<uint32_t>(max_coeff_bits));
+                           ctx->d_limbs, static_cast<uint32_t>(max_coeff_bits));
     else
         hipLaunchKernelGGL(compact_unpack_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(mat->data), static_cast<const uint8_t *>(d_payload), polys, N, sc,
-                           static_cast<uint32_t>(max_coeff_bits));
+                           ctx->d_limbs, static_cast<uint32_t>(max_coeff_bits));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // synchronous, like the reference; payload may be freed by the caller
     return 0;

@@ -228,15 +228,17 @@ class GpuDCRTPolyMatrix:
         coeff_count = self.nrow * self.ncol * self.params.ring_dimension()
         bits_upper = sum(q.bit_length() for q in self.params.moduli()[: self.level + 1])
         cap = (coeff_count * bits_upper + 7) // 8
-        payload = (C.c_uint8 * max(cap, 1))()
+        # worst-case capacity like the Rust side's vec![0u8; cap], but never touched beyond the payload: np.empty maps
+        # the pages lazily (bytearray(cap) zero-fills all of them, slicing a ctypes c_uint8 array builds a list)
+        head_room = 64  # the bincode header (6 varints) is written in front of the payload afterwards: one copy in total
+        backing = np.empty(head_room + max(cap, 1), dtype=np.uint8)
         max_bits, bpc, plen = C.c_uint16(0), C.c_uint16(0), C.c_size_t(0)
         st = _ffi.lib().gpu_matrix_store_compact_bytes(
-            self.raw, payload, cap, C.byref(max_bits), C.byref(bpc), C.byref(plen)
+            self.raw, C.c_void_p(backing.ctypes.data + head_room), cap, C.byref(max_bits), C.byref(bpc), C.byref(plen)
         )
         check_status(st, "gpu_matrix_store_compact_bytes")
         self.is_ntt = False  # the store converts in place (MatrixSerde.cu:1108-1118)
-        body = bytes(payload[: plen.value])
-        return b"".join(
+        header = b"".join(
             [
                 bytes([1, fmt]),
                 _bincode_varint(self.level),
@@ -244,10 +246,12 @@ class GpuDCRTPolyMatrix:
                 _bincode_varint(self.ncol),
                 _bincode_varint(max_bits.value),
                 _bincode_varint(bpc.value),
-                _bincode_varint(len(body)),
-                body,
+                _bincode_varint(plen.value),
             ]
         )
+        start = head_room - len(header)
+        backing[start:head_room] = np.frombuffer(header, dtype=np.uint8)
+        return backing[start : head_room + plen.value].tobytes()
 
     @classmethod
     def from_compact_bytes(cls, params, data: bytes) -> "GpuDCRTPolyMatrix":
@@ -267,7 +271,7 @@ class GpuDCRTPolyMatrix:
         assert level < params.crt_depth(), f"invalid compact matrix level: {level}"
         assert bpc == (max_bits + 7) // 8, "compact bytes_per_coeff mismatch"
         out = cls(params, nrow, ncol, level, False)
-        buf = (C.c_uint8 * max(plen, 1)).from_buffer_copy(payload if plen else b"\0")
+        buf = C.cast(C.c_char_p(payload if plen else b"\0"), C.POINTER(C.c_uint8))  # no copy: the call is synchronous
         st = _ffi.lib().gpu_matrix_load_compact_bytes(out.raw, buf, plen, max_bits)
         check_status(st, "gpu_matrix_load_compact_bytes")
         out.is_ntt = False
