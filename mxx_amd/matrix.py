@@ -165,7 +165,7 @@ class GpuDCRTPolyMatrix:
     def to_rns(self) -> np.ndarray:
         """`store_rns_bytes` in the current format (gpu_dcrt_poly.rs:576-596)."""
         n = self.params.ring_dimension()
-        out = np.zeros((self.nrow, self.ncol, self.level + 1, n), dtype=np.uint64)
+        out = np.empty((self.nrow, self.ncol, self.level + 1, n), dtype=np.uint64)  # every word is written below
         if out.size == 0:
             return out
         events = C.c_void_p()
@@ -281,7 +281,7 @@ class GpuDCRTPolyMatrix:
 
     def to_cpu_staging_bytes(self) -> bytes:
         """RNS snapshot framing (gpu_dcrt_poly.rs:1046-1061): (1u8, nrow, ncol, level, is_ntt, bytes_per_poly, bytes)."""
-        raw = self.to_rns().tobytes()
+        raw = memoryview(self.to_rns()).cast("B")  # joined below without an intermediate copy
         return b"".join(
             [
                 bytes([1]),

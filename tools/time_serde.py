@@ -40,3 +40,15 @@ for kind in ("bytearray", "pinned"):
         _ffi.check_status(_ffi.lib().gpu_matrix_store_compact_bytes(m.raw, buf, cap, C.byref(bits), C.byref(bpc), C.byref(plen)), "store")
         dt = time.perf_counter() - t0
     print(f"ABI store into {kind} host memory: {dt*1e3:.2f} ms for {plen.value/1e6:.1f} MB")
+
+# RNS staging bytes (to_cpu_staging_bytes / from_cpu_staging_bytes, gpu_dcrt_poly.rs:1046-1079): u64 wire layout
+for L, rows, cols in ((10, 8, 8), (10, 22, 50)):
+    p = mx.GpuDCRTPolyParams(n, mx.gen_crt_basis(n, L, 24), 12)
+    m = mx.GpuDCRTPolyUniformSampler().sample_uniform(p, rows, cols, mx.DistType.FinRingDist())
+    mx.gpu_device_sync()
+    bs = bl = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter(); blob = m.to_cpu_staging_bytes(); bs = min(bs, time.perf_counter() - t0)
+        t0 = time.perf_counter(); back = mx.GpuDCRTPolyMatrix.from_cpu_staging_bytes(p, blob); mx.gpu_device_sync(); bl = min(bl, time.perf_counter() - t0)
+    assert back == m
+    print(f"staging bytes {rows}x{cols} L={L}: {len(blob)/1e6:.0f} MB; store {bs*1e3:.1f} ms ({len(blob)/bs/1e9:.1f} GB/s), load {bl*1e3:.1f} ms ({len(blob)/bl/1e9:.1f} GB/s)")
