@@ -153,6 +153,9 @@ int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const Gpu
 /* out <- INTT(lhs o scalar_1x1): the point-wise product rides in the inverse transform's load (one HBM round
  * trip instead of two; replaces gpu_matrix_mul_scalar + gpu_matrix_intt_all).  out may be lhs.           */
 int gpupoly_matrix_mul_scalar_intt(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *scalar_1x1);
+/* out = src^T in one launch (the reference's wrapper issues rows*cols single-polynomial copy_block calls,
+ * src/matrix/gpu_dcrt_poly.rs:1190-1199).                                                                */
+int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src);
 /* hipEvent timing on the context's compute stream (bench.py's roofline leg). */
 int gpupoly_timer_start(GpuContext *ctx);
 int gpupoly_timer_stop(GpuContext *ctx, float *out_ms);

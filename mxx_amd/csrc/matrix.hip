@@ -69,6 +69,19 @@ __global__ void block_rect_kernel(W *__restrict__ dst, const W *__restrict__ src
     }
 }
 
+// out[c][r] = src[r][c], whole polynomials (all limbs contiguous): blockIdx.y = destination entry, 16 bytes per lane
+__global__ void transpose_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t src_rows, size_t src_cols,
+                                 size_t vec_per_poly) {
+    const size_t entry = static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y;  // destination index c * src_rows + r
+    if (entry >= src_rows * src_cols) return;
+    const size_t c = entry / src_rows, r = entry - c * src_rows;
+    const uint4 *s = src + (r * src_cols + c) * vec_per_poly;
+    uint4 *d = dst + entry * vec_per_poly;
+    for (size_t v = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; v < vec_per_poly;
+         v += static_cast<size_t>(gridDim.x) * blockDim.x)
+        d[v] = s[v];
+}
+
 // int64 [poly][N] -> residues in every limb of `out`
 template <typename W>
 __global__ void scatter_i64_kernel(W *__restrict__ dst, const int64_t *__restrict__ vals,
@@ -240,6 +253,44 @@ extern "C" int gpu_matrix_add_block(GpuMatrix *out, const GpuMatrix *src, size_t
                                     size_t src_row, size_t src_col, size_t rows, size_t cols) {
     ABI_GUARD_BEGIN
     return launch_copy_block(out, src, dst_row, dst_col, src_row, src_col, rows, cols, true);
+    ABI_GUARD_END
+}
+
+// Transpose in ONE launch (extension).  The reference's wrapper issues rows x cols single-polynomial
+// gpu_matrix_copy_block calls (src/matrix/gpu_dcrt_poly.rs:1190-1199): 3600 launches for a 30 x 120 matrix.
+extern "C" int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src) {
+    ABI_GUARD_BEGIN
+    if (!out || !src) return set_error("gpupoly_matrix_transpose: null matrix");
+    if (out == src) return set_error("gpupoly_matrix_transpose: output must not alias the source");
+    if (out->ctx != src->ctx || out->level != src->level) return set_error("gpupoly_matrix_transpose: context / level mismatch");
+    if (out->rows != src->cols || out->cols != src->rows) return set_error("gpupoly_matrix_transpose: shape mismatch");
+    out->format = src->format;
+    const size_t polys = matrix_polys(src);
+    if (polys == 0) return 0;
+    GpuContext *ctx = src->ctx;
+    if (ctx_activate(ctx)) return 1;
+    const size_t poly_bytes = matrix_limbs(src) * static_cast<size_t>(ctx->N) * ctx->word_bytes;
+    if (poly_bytes % 16 != 0 || src->rows == 1 || src->cols == 1) {
+        // a vector's transpose is the same bytes; tiny rings (N * word < 16 bytes) go entry by entry
+        if (src->rows == 1 || src->cols == 1) {
+            HIP_TRY(hipMemcpyAsync(out->data, src->data, src->bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            return 0;
+        }
+        for (size_t r = 0; r < src->rows; ++r)
+            for (size_t c = 0; c < src->cols; ++c)
+                HIP_TRY(hipMemcpyAsync(static_cast<char *>(out->data) + (c * src->rows + r) * poly_bytes,
+                                       static_cast<const char *>(src->data) + (r * src->cols + c) * poly_bytes, poly_bytes,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    const size_t vec_per_poly = poly_bytes / 16;
+    const unsigned gx = static_cast<unsigned>(std::min<size_t>((vec_per_poly + 255) / 256, 64));
+    const size_t gy = std::min<size_t>(polys, 65535), gz = (polys + gy - 1) / gy;
+    if (gz > 65535) return set_error("gpupoly_matrix_transpose: matrix too large");
+    hipLaunchKernelGGL(transpose_kernel, dim3(gx, static_cast<unsigned>(gy), static_cast<unsigned>(gz)), dim3(256), 0, ctx->stream,
+                       static_cast<uint4 *>(out->data), static_cast<const uint4 *>(src->data), src->rows, src->cols, vec_per_poly);
+    HIP_TRY(hipGetLastError());
+    return 0;
     ABI_GUARD_END
 }
 

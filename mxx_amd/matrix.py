@@ -416,10 +416,11 @@ class GpuDCRTPolyMatrix:
         return [self.entry(i, j) for i in range(self.nrow)]
 
     def transpose(self) -> "GpuDCRTPolyMatrix":
+        """One launch (gpupoly_matrix_transpose); the reference loops nrow*ncol single-entry copy_block calls
+        (gpu_dcrt_poly.rs:1190-1199)."""
         out = GpuDCRTPolyMatrix(self.params, self.ncol, self.nrow, self.level, self.is_ntt)
-        for i in range(self.nrow):
-            for j in range(self.ncol):
-                out.copy_block_from(self, j, i, i, j, 1, 1)
+        if self.nrow and self.ncol:
+            check_status(_ffi.lib().gpupoly_matrix_transpose(out.raw, self.raw), "gpupoly_matrix_transpose")
         return out
 
     def _same_domain(self, others):

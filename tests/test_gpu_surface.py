@@ -307,3 +307,19 @@ def test_matmul_lazy_window_worst_case_both_operands(gpu, oracle, hip_env, path)
     hip_env.set("MXX_HIP_MATMUL_PATH", path)
     got = (gpu.GpuDCRTPolyMatrix.from_rns(p, a, True) * gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)).to_rns()
     assert np.array_equal(got, oracle.matmul(a, b, moduli))
+
+
+@pytest.mark.parametrize("n,depth,bits,shape", [(4, 2, 17, (3, 5)), (2, 1, 17, (4, 3)), (128, 3, 24, (1, 6)), (128, 3, 24, (7, 1)),
+                                                (1024, 2, 51, (5, 9)), (16384, 2, 24, (6, 4))])
+def test_transpose_one_launch(gpu, oracle, n, depth, bits, shape):
+    """gpupoly_matrix_transpose (one launch instead of rows*cols copy_block calls), including rings so small that a
+    polynomial is shorter than 16 bytes and the vector shapes whose transpose is the same bytes."""
+    moduli = oracle.gen_crt_basis(n, depth, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 4)
+    a = rand_matrix(oracle, 900, shape[0], shape[1], moduli, n)
+    for fmt in (False, True):
+        ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, fmt)
+        t = ga.transpose()
+        assert t.size() == (shape[1], shape[0]) and t.is_ntt == fmt
+        assert np.array_equal(t.to_rns(), a.transpose(1, 0, 2, 3))
+        assert t.transpose() == ga
