@@ -161,6 +161,33 @@ __device__ __forceinline__ uint64_t rng_next_u64(ChaChaRng &rng) {
     return v;
 }
 
+// Persistent lanes without a shared counter: every wave owns one contiguous chunk of elements and hands them out
+// in order; the lanes that ask in the same step get consecutive numbers (ballot + prefix count, the running count
+// stays in a scalar register).  Must be called by the whole wave.  Which lane computes an element never matters:
+// every element's randomness is keyed by its own index.
+struct WaveChunk {
+    size_t base;     // first element of this wave's chunk
+    uint32_t len;    // elements in it
+    uint32_t next;   // handed out so far (wave-uniform)
+};
+
+__device__ __forceinline__ WaveChunk wave_chunk(size_t total, uint32_t per_lane) {
+    const size_t wave = static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    WaveChunk c;
+    c.base = wave * 64u * per_lane;
+    c.len = c.base < total ? static_cast<uint32_t>(std::min<size_t>(64u * static_cast<size_t>(per_lane), total - c.base)) : 0u;
+    c.next = 0;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t wave_take(WaveChunk &c, bool want) {
+    const uint64_t m = __ballot(want);
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    const uint32_t e = c.next + before;
+    c.next += static_cast<uint32_t>(__popcll(m));
+    return e;
+}
+
 __device__ __forceinline__ double u64_to_open01(uint64_t w) {
     const double scale = 1.0 / 9007199254740992.0;  // 2^-53
     double u = static_cast<double>(w >> 11) * scale;

@@ -61,22 +61,18 @@ __global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict_
         dst[static_cast<size_t>(l) * N] = signed_to_residue_mu<W>(z, limbs[l].q, limbs[l].mu64);
 }
 
-// discrete Gaussian: persistent lanes (rng.h).  Block b owns coefficients [b*256*per_lane, +256*per_lane);
-// its lanes take them one at a time from a shared counter, each coefficient with its own stream
+// discrete Gaussian: persistent lanes (rng.h).  Wave w owns coefficients [w*64*per_lane, +64*per_lane);
+// its lanes take them one at a time (wave_take), each coefficient with its own stream
 // (sub-key shared by all).  Lanes finish at different times, so a lane's store is a lone 8 bytes:
 // it goes to a compact int64 staging array ([poly][N]) that a coalesced pass expands into the L
 // residues per coefficient (storing the residues from here cost a 32-byte HBM write per limb).
 __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
-    __shared__ uint32_t next_e;
-    if (threadIdx.x == 0) next_e = 0;
-    __syncthreads();
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];  // exactly 32 KB: five workgroups per CU
     const size_t total = polys << logN;  // polys < 2^32 (checked by the launcher)
     const size_t N = static_cast<size_t>(1) << logN;
-    const size_t chunk_base = static_cast<size_t>(blockIdx.x) * 256u * per_lane;
-    const uint32_t chunk_len = static_cast<uint32_t>(std::min<size_t>(256u * static_cast<size_t>(per_lane), total - chunk_base));
+    WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
     KarneyFsm f;
@@ -86,12 +82,13 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
     for (uint32_t step = 0;; ++step) {
         if ((step & 3) == 0) {
             if ((step & 7) == 0) {
-                if (f.st == KS_DONE) {  // write the finished coefficient, open the next one's stream
-                    if (have) stage[idx] = f.result;
-                    const uint32_t e = atomicAdd(&next_e, 1u);
-                    have = e < chunk_len;
+                const bool take = f.st == KS_DONE;  // write the finished coefficient, open the next one's stream
+                if (take && have) stage[idx] = f.result;
+                const uint32_t e = wave_take(chunk, take);
+                if (take) {
+                    have = e < chunk.len;
                     if (have) {
-                        idx = chunk_base + e;
+                        idx = chunk.base + e;
                         const uint32_t p = static_cast<uint32_t>(idx >> logN);
                         const uint32_t row = p / local_ncol, lcol = p - row * local_ncol;
                         rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx & (N - 1)) + 1);

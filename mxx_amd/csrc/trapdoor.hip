@@ -227,27 +227,23 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     }
 }
 
-// Pass 2: the dpt Karney integers of every element.  Block b owns elements [b*256*per_lane,
-// +256*per_lane) and its lanes take them one at a time from a shared counter.
+// Pass 2: the dpt Karney integers of every element.  Wave w owns elements [w*64*per_lane,
+// +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
 template <typename W, int MAXD>
-__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ src,
+__global__ void __launch_bounds__(256, MAXD <= 2 ? 5 : 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ src,
                                         const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
                                         uint32_t L, uint32_t logN, uint32_t dpt, uint32_t base_bits, double c,
                                         KarneyDivisor div_sigma, uint32_t per_lane) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
-    __shared__ uint32_t next_e;
-    if (threadIdx.x == 0) next_e = 0;
-    __syncthreads();
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];  // exactly 32 KB: five workgroups per CU
     const uint64_t base = 1ull << base_bits;
     const double base_f = static_cast<double>(base);
     const double sigma = c / (base_f + 1.0);
     const int last = static_cast<int>(dpt) - 1;
     const uint32_t nleft = 8 - 2 * dpt;
-    const size_t chunk_base = static_cast<size_t>(blockIdx.x) * 256u * per_lane;
-    const uint32_t chunk_len = static_cast<uint32_t>(std::min<size_t>(256u * static_cast<size_t>(per_lane), total - chunk_base));
+    WaveChunk chunk = wave_chunk(total, per_lane);
 
     ChaChaRng rng;
     rng_init_keyed(rng, ring, ChaChaKey{}, 0, 0);
@@ -294,29 +290,30 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                 }
             }
             if ((step & 7) == 0) {
-                if (f.st == KS_DONE && fin) {  // element complete: write its digits, take the next one
-                    if (have) {
-                        int64_t z_prev = 0;
+                const bool take = f.st == KS_DONE && fin;  // element complete: write its digits, take the next one
+                if (take && have) {
+                    int64_t z_prev = 0;
 #pragma unroll
-                        for (int d = 0; d < MAXD; ++d) {
-                            if (d < (int)dpt) {
-                                const int64_t md = static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1));
-                                const int64_t vd = static_cast<int64_t>((value >> (base_bits * d)) & (base - 1));
-                                const int64_t zd = d < last ? z[d] : z_last;
-                                int64_t digit;
-                                if (dpt == 1) digit = static_cast<int64_t>(base) * zd + md * zd + vd;
-                                else if (d == 0) digit = static_cast<int64_t>(base) * zd + md * z_last + vd;
-                                else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
-                                else digit = md * z_last - z_prev + vd;
-                                z_prev = zd;
-                                stage[idx * dpt + d] = digit;
-                            }
+                    for (int d = 0; d < MAXD; ++d) {
+                        if (d < (int)dpt) {
+                            const int64_t md = static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1));
+                            const int64_t vd = static_cast<int64_t>((value >> (base_bits * d)) & (base - 1));
+                            const int64_t zd = d < last ? z[d] : z_last;
+                            int64_t digit;
+                            if (dpt == 1) digit = static_cast<int64_t>(base) * zd + md * zd + vd;
+                            else if (d == 0) digit = static_cast<int64_t>(base) * zd + md * z_last + vd;
+                            else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
+                            else digit = md * z_last - z_prev + vd;
+                            z_prev = zd;
+                            stage[idx * dpt + d] = digit;
                         }
                     }
-                    const uint32_t e = atomicAdd(&next_e, 1u);
-                    have = e < chunk_len;
+                }
+                const uint32_t e = wave_take(chunk, take);
+                if (take) {
+                    have = e < chunk.len;
                     if (have) {
-                        idx = chunk_base + e;
+                        idx = chunk.base + e;
                         const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
                         const uint32_t pt = static_cast<uint32_t>(idx >> logN);
                         const uint32_t p = pt / L, t = pt - p * L;
@@ -602,12 +599,8 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
                                        const KarneyDivisor *__restrict__ div_base, uint32_t m, uint32_t cols, uint32_t L,
                                        uint32_t logN, uint64_t q0, double c_scale, ChaChaKey key, size_t total,
                                        uint32_t per_lane) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
-    __shared__ uint32_t next_e;
-    if (threadIdx.x == 0) next_e = 0;
-    __syncthreads();
-    const size_t chunk_base = static_cast<size_t>(blockIdx.x) * 256u * per_lane;
-    const uint32_t chunk_len = static_cast<uint32_t>(std::min<size_t>(256u * static_cast<size_t>(per_lane), total - chunk_base));
+    __shared__ uint64_t ring[256 * RNG_RING_WORDS];  // exactly 32 KB: five workgroups per CU
+    WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
     KarneyFsm f;
@@ -640,11 +633,12 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
                 }
             }
             if ((step & 7) == 0) {
-                if (f.st == KS_DONE && fin) {
-                    const uint32_t e = atomicAdd(&next_e, 1u);
-                    have = e < chunk_len;
+                const bool take = f.st == KS_DONE && fin;
+                const uint32_t e = wave_take(chunk, take);
+                if (take) {
+                    have = e < chunk.len;
                     if (have) {
-                        const size_t idx = chunk_base + e;
+                        const size_t idx = chunk.base + e;
                         col = static_cast<uint32_t>(idx >> logN);
                         i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
 #pragma unroll
