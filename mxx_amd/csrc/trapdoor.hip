@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 // +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
 template <typename W, int MAXD>
-__global__ void __launch_bounds__(256, MAXD <= 2 ? 5 : 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ src,
+__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ src,
                                         const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
