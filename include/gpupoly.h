@@ -156,6 +156,12 @@ int gpupoly_matrix_mul_scalar_intt(GpuMatrix *out, const GpuMatrix *lhs, const G
 /* out = src^T in one launch (the reference's wrapper issues rows*cols single-polynomial copy_block calls,
  * src/matrix/gpu_dcrt_poly.rs:1190-1199).                                                                */
 int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src);
+/* G^-1 of a freshly sampled rows x cols matrix: out is (rows*k) x cols, k = digits per entry (small != 0: the digits
+ * of limb 0 only).  Same samples as gpu_matrix_sample_distribution, same digits as gpu_matrix_decompose_base(_small);
+ * the sample's NTT and the decomposition's copy + INTT are skipped (replaces the pairs in
+ * src/sampler/gpu.rs:91-115, `sample_hash_decomposed` / `sample_hash_small_decomposed`).                   */
+int gpupoly_matrix_sample_decomposed(GpuMatrix *out, int dist_type, double sigma, GpuRngSeed seed, uint32_t base_bits,
+                                     int small);
 /* hipEvent timing on the context's compute stream (bench.py's roofline leg). */
 int gpupoly_timer_start(GpuContext *ctx);
 int gpupoly_timer_stop(GpuContext *ctx, float *out_ms);

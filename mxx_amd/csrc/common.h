@@ -151,6 +151,9 @@ inline size_t matrix_polys(const GpuMatrix *m) { return m->rows * m->cols; }
 inline size_t matrix_limbs(const GpuMatrix *m) { return static_cast<size_t>(m->level) + 1; }
 inline size_t matrix_words(const GpuMatrix *m) { return matrix_polys(m) * matrix_limbs(m) * static_cast<size_t>(m->ctx->N); }
 
+// sampling.hip: fills `out` with samples; keep_coeff leaves them in the coefficient domain
+int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t full_ncol, size_t col_offset, bool keep_coeff);
+
 int ctx_activate(const GpuContext *ctx);                   // hipSetDevice
 int ctx_alloc(GpuContext *ctx, size_t bytes, void **out);  // stream-ordered
 void ctx_free(GpuContext *ctx, void *ptr);                 // stream-ordered

@@ -247,3 +247,38 @@ extern "C" int gpu_matrix_fill_small_decomposed_identity_chunk(GpuMatrix *out, c
     return 0;
     ABI_GUARD_END
 }
+
+// Extension: G^-1 of a freshly sampled matrix in one call.  The reference samples (coefficients -> NTT), then
+// decomposes (INTT of a copy -> digits -> NTT): src/sampler/gpu.rs:91-115 (`sample_hash_decomposed`,
+// `sample_hash_small_decomposed`).  Here the samples stay coefficients and go straight into the digit transform:
+// the source's NTT, its copy and its INTT are never run.  `out` is (rows * k) x cols, created EVAL or COEFF like
+// the output of gpu_matrix_decompose_base; the samples are those of gpu_matrix_sample_distribution(rows x cols).
+extern "C" int gpupoly_matrix_sample_decomposed(GpuMatrix *out, int dist_type, double sigma, GpuRngSeed seed,
+                                                uint32_t base_bits, int small) {
+    ABI_GUARD_BEGIN
+    if (!out) return set_error("gpupoly_matrix_sample_decomposed: null matrix");
+    if (base_bits == 0) return set_error("base_bits must be non-zero in gpupoly_matrix_sample_decomposed");
+    GpuContext *ctx = out->ctx;
+    const size_t L = matrix_limbs(out);
+    const uint32_t dpt = (ctx->crt_bits + base_bits - 1) / base_bits;
+    const size_t k = small ? dpt : static_cast<size_t>(dpt) * L;
+    if (out->rows % k) return set_error("gpupoly_matrix_sample_decomposed: output rows must be a multiple of the digit count");
+    GpuMatrix src;
+    src.ctx = ctx;
+    src.level = out->level;
+    src.rows = out->rows / k;
+    src.cols = out->cols;
+    src.bytes = src.rows * src.cols * L * static_cast<size_t>(ctx->N) * static_cast<size_t>(ctx->word_bytes);
+    if (matrix_polys(&src) == 0) {
+        out->format = GPU_POLY_FORMAT_EVAL;
+        return 0;
+    }
+    if (ctx_activate(ctx)) return 1;
+    CtxBlock block(ctx);
+    if (block.alloc(src.bytes)) return 1;
+    src.data = block.ptr;
+    int rc = sample_impl(&src, dist_type, sigma, seed, src.cols, 0, true);
+    if (rc == 0) rc = decompose_impl(&src, base_bits, out, small != 0);
+    return rc;
+    ABI_GUARD_END
+}

@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
     }
 }
 
-static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t full_ncol, size_t col_offset) {
+// keep_coeff: leave the samples as coefficients (for a caller that decomposes them next) instead of finishing in EVAL
+int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t full_ncol, size_t col_offset, bool keep_coeff) {
     if (!out) return set_error("gpu_matrix_sample_distribution: null matrix");
     if (dist < GPU_MATRIX_DIST_UNIFORM || dist > GPU_MATRIX_DIST_TERNARY)
         return set_error("gpu_matrix_sample_distribution: invalid dist_type");
@@ -115,7 +116,7 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
     if (col_offset + out->cols > full_ncol)
         return set_error("gpu_matrix_sample_distribution_columns: column window out of range");
     GpuContext *ctx = out->ctx;
-    out->format = GPU_POLY_FORMAT_EVAL;
+    out->format = keep_coeff ? GPU_POLY_FORMAT_COEFF : GPU_POLY_FORMAT_EVAL;
     const size_t polys = matrix_polys(out);
     if (polys == 0) return 0;
     if (ctx_activate(ctx)) return 1;
@@ -150,6 +151,7 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
                                L, N, dist, seed);
     }
     HIP_TRY(hipGetLastError());
+    if (keep_coeff) return 0;
     // samples are coefficients; callers always get EVAL (MatrixSampling.cu:463-469)
     return launch_ntt(ctx, out->data, polys * L, static_cast<int>(L), false);
 }
@@ -157,13 +159,13 @@ static int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, 
 extern "C" int gpu_matrix_sample_distribution(GpuMatrix *out, int dist_type, double sigma, GpuRngSeed seed) {
     ABI_GUARD_BEGIN
     if (!out) return set_error("gpu_matrix_sample_distribution: null matrix");
-    return sample_impl(out, dist_type, sigma, seed, out->cols, 0);
+    return sample_impl(out, dist_type, sigma, seed, out->cols, 0, false);
     ABI_GUARD_END
 }
 
 extern "C" int gpu_matrix_sample_distribution_columns(GpuMatrix *out, int dist_type, double sigma, GpuRngSeed seed,
                                                       size_t full_ncol, size_t col_offset) {
     ABI_GUARD_BEGIN
-    return sample_impl(out, dist_type, sigma, seed, full_ncol, col_offset);
+    return sample_impl(out, dist_type, sigma, seed, full_ncol, col_offset, false);
     ABI_GUARD_END
 }

@@ -694,6 +694,18 @@ class GpuDCRTPolyMatrix:
         check_status(st, "gpu_matrix_sample_distribution_columns")
         return out
 
+    @classmethod
+    def sample_distribution_decomposed(cls, params, nrow, ncol, dist: int, sigma: float, seed: GpuRngSeed, small=False):
+        """G^-1 (or the small G^-1) of `sample_distribution(params, nrow, ncol, ...)` through the
+        `gpupoly_matrix_sample_decomposed` extension: the samples never leave the coefficient domain."""
+        k = -(-params.crt_bits() // params.base_bits()) if small else params.modulus_digits()
+        out = cls.new_empty(params, nrow * k, ncol)
+        if nrow == 0 or ncol == 0:
+            return out
+        st = _ffi.lib().gpupoly_matrix_sample_decomposed(out.raw, dist, sigma, seed, params.base_bits(), 1 if small else 0)
+        check_status(st, "gpupoly_matrix_sample_decomposed")
+        return out
+
     def gauss_samp_gq_arb_base(self, c: float, dgg_stddev: float, seed: GpuRngSeed) -> "GpuDCRTPolyMatrix":
         """Consumes self (gpu_dcrt_poly.rs:509-528)."""
         out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow * self.params.modulus_digits(), self.ncol)

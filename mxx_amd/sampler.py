@@ -127,7 +127,11 @@ class GpuDCRTPolyHashSampler:
         return sample_gpu_matrix_with_seed_columns(params, nrow, total_ncol, col_start, col_len, dist, seed)
 
     def sample_hash_decomposed(self, params, key, tag, nrow, ncol, dist):
-        return self.sample_hash(params, key, tag, nrow, ncol, dist).decompose()
+        """== sample_hash(...).decompose() (src/sampler/gpu.rs:91-103), in one extension call."""
+        seed = hash_seed_for_matrix(key, tag, self.hash_name)
+        return GpuDCRTPolyMatrix.sample_distribution_decomposed(params, nrow, ncol, dist.as_ffi(), dist.sigma, seed)
 
     def sample_hash_small_decomposed(self, params, key, tag, nrow, ncol, dist):
-        return self.sample_hash(params, key, tag, nrow, ncol, dist).small_decompose()
+        """== sample_hash(...).small_decompose() (src/sampler/gpu.rs:104-115), in one extension call."""
+        seed = hash_seed_for_matrix(key, tag, self.hash_name)
+        return GpuDCRTPolyMatrix.sample_distribution_decomposed(params, nrow, ncol, dist.as_ffi(), dist.sigma, seed, True)

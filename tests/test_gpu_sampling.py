@@ -237,3 +237,20 @@ def test_preimage_extend(gpu, oracle):
     target = us.sample_uniform(p, 2, 2, gpu.DistType.FinRingDist())
     x = sampler.preimage_extend(p, td, A, ext, target)
     assert A.concat_columns([ext]) * x == target
+
+
+@pytest.mark.parametrize("n,depth,bits,base", [(128, 2, 17, 4), (64, 2, 51, 17), (16384, 3, 24, 12), (1024, 3, 24, 7)])
+def test_sample_decomposed_extension_equals_sample_then_decompose(gpu, oracle, n, depth, bits, base):
+    """gpupoly_matrix_sample_decomposed == sample_distribution(...).decompose() / .small_decompose() for every
+    distribution (src/sampler/gpu.rs:91-115), EVAL and bit for bit."""
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    key = bytes(range(32))
+    hs = gpu.GpuDCRTPolyHashSampler()
+    for dist in (gpu.DistType.FinRingDist(), gpu.DistType.GaussDist(4.578), gpu.DistType.BitDist(), gpu.DistType.TernaryDist()):
+        a = hs.sample_hash(p, key, b"dec", 2, 3, dist)
+        full = hs.sample_hash_decomposed(p, key, b"dec", 2, 3, dist)
+        small = hs.sample_hash_small_decomposed(p, key, b"dec", 2, 3, dist)
+        assert full.is_ntt and small.is_ntt
+        assert full == a.decompose()
+        assert small == a.small_decompose()
+    assert hs.sample_hash_decomposed(p, key, b"dec", 0, 3, gpu.DistType.BitDist()).size() == (0, 3)
