@@ -150,6 +150,16 @@ int gpu_poly_load_compact_bytes(GpuMatrix *poly, const uint8_t *payload, size_t 
  * memory allows, then one product into `out`.  The EVAL-form digit matrix IS written once and read once (a full
  * fusion would need 8 x 16384 accumulators per workgroup).                          */
 int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);
+/* lhs * small-G^-1(rhs) (digits of limb 0 only): replaces the column-chunk loop of mul_decompose_small
+ * (src/matrix/gpu_dcrt_poly.rs:1495-1574).                                                                */
+int gpupoly_matrix_mul_decompose_small(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);
+/* lhs * (I_identity_size (x) rhs): one product per identity block, written in place, no slice / concat copies for
+ * row-vector operands (replaces src/matrix/gpu_dcrt_poly.rs:1374-1390).                                     */
+int gpupoly_matrix_mul_tensor_identity(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, size_t identity_size);
+/* lhs * (I_identity_size (x) G^-1(rhs)): G^-1(rhs) is built ONCE and reused by every identity block; the reference
+ * decomposes every column again for every block (src/matrix/gpu_dcrt_poly.rs:1392-1412).                    */
+int gpupoly_matrix_mul_tensor_identity_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs,
+                                                 size_t identity_size, uint32_t base_bits);
 /* out <- INTT(lhs o scalar_1x1): the point-wise product rides in the inverse transform's load (one HBM round
  * trip instead of two; replaces gpu_matrix_mul_scalar + gpu_matrix_intt_all).  out may be lhs.           */
 int gpupoly_matrix_mul_scalar_intt(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *scalar_1x1);

@@ -94,6 +94,9 @@ SIGNATURES = {
     "gpu_poly_store_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(_sz)]),
     "gpu_poly_load_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.c_uint16]),
     "gpupoly_matrix_mul_decompose": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "gpupoly_matrix_mul_decompose_small": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "gpupoly_matrix_mul_tensor_identity": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "gpupoly_matrix_mul_tensor_identity_decompose": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32]),
     "gpupoly_matrix_mul_scalar_intt": (C.c_int, [_vp, _vp, _vp]),
     "gpupoly_matrix_transpose": (C.c_int, [_vp, _vp]),
     "gpupoly_matrix_sample_decomposed": (C.c_int, [_vp, C.c_int, C.c_double, GpuRngSeed, C.c_uint32, C.c_int]),

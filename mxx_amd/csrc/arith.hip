@@ -512,6 +512,105 @@ extern "C" int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
     ABI_GUARD_END
 }
 
+// out = lhs * (I_identity (x) X) with X = rhs (mode 0), G^-1(rhs) (mode 1) or the small G^-1(rhs) (mode 2).
+// X is built once per column chunk and used for every identity block: the reference's wrappers recompute the
+// decomposition of every column for every block (src/matrix/gpu_dcrt_poly.rs:1392-1412).  Row-vector operands
+// (one row: BGG encodings) are multiplied in place through views; taller ones go through one reused slice buffer.
+static GpuMatrix matrix_view(const GpuMatrix *m, size_t first_poly, size_t rows, size_t cols, size_t poly_bytes) {
+    GpuMatrix v;
+    v.ctx = m->ctx;
+    v.level = m->level;
+    v.rows = rows;
+    v.cols = cols;
+    v.format = m->format;
+    v.data = static_cast<char *>(m->data) + first_poly * poly_bytes;
+    v.bytes = rows * cols * poly_bytes;
+    return v;
+}
+
+static int mul_tensor_identity_impl(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, size_t identity_size,
+                                    int mode, uint32_t base_bits, const char *who) {
+    if (!out || !lhs || !rhs) return set_error(std::string(who) + ": null matrix");
+    if (out->ctx != lhs->ctx || out->ctx != rhs->ctx) return set_error(std::string(who) + ": context mismatch");
+    if (out->level != lhs->level || out->level != rhs->level) return set_error(std::string(who) + ": level mismatch");
+    if (mode != 0 && (base_bits == 0 || base_bits >= 63)) return set_error(std::string(who) + ": invalid base_bits");
+    if (identity_size == 0) return set_error(std::string(who) + ": identity_size must be positive");
+    if (out == lhs || out == rhs) return set_error(std::string(who) + ": output must not alias an input");
+    GpuContext *ctx = out->ctx;
+    const size_t L = matrix_limbs(out);
+    const size_t dpt = mode == 0 ? 1 : (ctx->crt_bits + base_bits - 1) / base_bits;
+    const size_t k = mode == 0 ? 1 : (mode == 1 ? dpt * L : dpt);
+    const size_t w = rhs->rows * k;  // columns of lhs per identity block
+    if (lhs->cols != w * identity_size || out->rows != lhs->rows || out->cols != rhs->cols * identity_size)
+        return set_error(std::string(who) + ": shape mismatch");
+    if (lhs->format != GPU_POLY_FORMAT_EVAL || (mode == 0 && rhs->format != GPU_POLY_FORMAT_EVAL))
+        return set_error(std::string(who) + " requires Eval format");
+    out->format = GPU_POLY_FORMAT_EVAL;
+    if (matrix_polys(out) == 0) return 0;
+    if (ctx_activate(ctx)) return 1;
+    if (w == 0) {
+        HIP_TRY(hipMemsetAsync(out->data, 0, out->bytes, ctx->stream));
+        return 0;
+    }
+    const size_t poly_bytes = L * static_cast<size_t>(ctx->N) * ctx->word_bytes;
+    size_t chunk = rhs->cols;
+    if (mode != 0) {
+        // digit-matrix budget: a third of what the device could give us now (cached blocks count as available)
+        size_t free_b = 0, total_b = 0, budget = size_t(8) << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max(budget, (free_b + ctx->cached_bytes) / 3);
+        else (void)hipGetLastError();
+        chunk = std::min(rhs->cols, std::max<size_t>(1, budget / (w * poly_bytes)));
+    }
+    const bool row_vector = lhs->rows == 1;
+    const bool in_place = row_vector || (identity_size == 1 && chunk == rhs->cols);
+    GpuMatrix *lhs_buf = nullptr, *prod = nullptr;
+    int rc = 0;
+    if (!row_vector && identity_size > 1) rc = gpu_matrix_create(ctx, out->level, lhs->rows, w, GPU_POLY_FORMAT_EVAL, &lhs_buf);
+    if (!rc && !in_place) rc = gpu_matrix_create(ctx, out->level, lhs->rows, chunk, GPU_POLY_FORMAT_EVAL, &prod);
+    for (size_t c0 = 0; !rc && c0 < rhs->cols; c0 += chunk) {
+        const size_t cw = std::min(chunk, rhs->cols - c0);
+        const bool whole = cw == rhs->cols;
+        GpuMatrix *slice = nullptr, *dec = nullptr;
+        if (!whole) {
+            rc = gpu_matrix_create(ctx, out->level, rhs->rows, cw, rhs->format, &slice);
+            if (!rc) rc = gpu_matrix_copy_block(slice, rhs, 0, 0, 0, c0, rhs->rows, cw);
+        }
+        const GpuMatrix *x = whole ? rhs : slice;
+        if (!rc && mode != 0) {
+            rc = gpu_matrix_create(ctx, out->level, w, cw, GPU_POLY_FORMAT_EVAL, &dec);
+            if (!rc) rc = mode == 1 ? gpu_matrix_decompose_base(x, base_bits, dec) : gpu_matrix_decompose_base_small(x, base_bits, dec);
+            x = dec;
+        }
+        for (size_t i = 0; !rc && i < identity_size; ++i) {
+            GpuMatrix lhs_view = matrix_view(lhs, i * w, 1, w, poly_bytes);
+            const GpuMatrix *a = lhs;
+            if (row_vector) a = &lhs_view;
+            else if (identity_size > 1) {
+                rc = gpu_matrix_copy_block(lhs_buf, lhs, 0, 0, 0, i * w, lhs->rows, w);
+                a = lhs_buf;
+            }
+            if (rc) break;
+            if (row_vector) {
+                GpuMatrix out_view = matrix_view(out, i * rhs->cols + c0, 1, cw, poly_bytes);
+                rc = gpu_matrix_mul(&out_view, a, x);
+            } else if (in_place) {
+                rc = gpu_matrix_mul(out, a, x);
+            } else {
+                GpuMatrix prod_view = matrix_view(prod, 0, lhs->rows, cw, poly_bytes);
+                rc = gpu_matrix_mul(&prod_view, a, x);
+                if (!rc) rc = gpu_matrix_copy_block(out, &prod_view, 0, i * rhs->cols + c0, 0, 0, lhs->rows, cw);
+            }
+        }
+        gpu_matrix_destroy(slice);
+        gpu_matrix_destroy(dec);
+    }
+    gpu_matrix_destroy(lhs_buf);
+    gpu_matrix_destroy(prod);
+    if (rc) return rc;
+    out->format = GPU_POLY_FORMAT_EVAL;
+    return 0;
+}
+
 // S * G^-1(B) in one ABI call (extension; the Rust wrapper loops column chunks of width
 // MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH = 1, src/matrix/gpu_dcrt_poly.rs:1414-1493: slice, decompose, product,
 // copy_block per chunk, re-reading all of S for every chunk - 80.9 ms for (8x1024) * G^-1(64x64) at n = 2^14, L = 8).
@@ -526,49 +625,28 @@ extern "C" int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
 extern "C" int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs,
                                             uint32_t base_bits) {
     ABI_GUARD_BEGIN
-    if (!out || !lhs || !rhs) return set_error("gpupoly_matrix_mul_decompose: null matrix");
-    if (out->ctx != lhs->ctx || out->ctx != rhs->ctx) return set_error("gpupoly_matrix_mul_decompose: context mismatch");
-    if (out->level != lhs->level || out->level != rhs->level)
-        return set_error("gpupoly_matrix_mul_decompose: level mismatch");
-    if (base_bits == 0 || base_bits >= 63) return set_error("gpupoly_matrix_mul_decompose: invalid base_bits");
-    if (out == lhs || out == rhs) return set_error("gpupoly_matrix_mul_decompose: output must not alias an input");
-    GpuContext *ctx = out->ctx;
-    const size_t L = matrix_limbs(out);
-    const size_t k = static_cast<size_t>((ctx->crt_bits + base_bits - 1) / base_bits) * L;
-    if (lhs->cols != rhs->rows * k || out->rows != lhs->rows || out->cols != rhs->cols)
-        return set_error("gpupoly_matrix_mul_decompose: shape mismatch");
-    if (lhs->format != GPU_POLY_FORMAT_EVAL) return set_error("gpupoly_matrix_mul_decompose requires Eval format");
-    out->format = GPU_POLY_FORMAT_EVAL;
-    if (matrix_polys(out) == 0) return 0;
-    if (ctx_activate(ctx)) return 1;
-    const size_t poly_bytes = L * static_cast<size_t>(ctx->N) * ctx->word_bytes;
-    // digit-matrix budget: a third of what the device could give us now (cached blocks count as available)
-    size_t free_b = 0, total_b = 0, budget = size_t(8) << 30;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max(budget, (free_b + ctx->cached_bytes) / 3);
-    else (void)hipGetLastError();
-    size_t chunk = std::max<size_t>(1, budget / std::max<size_t>(1, rhs->rows * k * poly_bytes));
-    chunk = std::min(chunk, rhs->cols);
-    for (size_t c0 = 0; c0 < rhs->cols; c0 += chunk) {
-        const size_t cw = std::min(chunk, rhs->cols - c0);
-        const bool whole = cw == rhs->cols;
-        GpuMatrix *slice = nullptr, *dec = nullptr, *prod = nullptr;
-        int rc = 0;
-        if (!whole) {
-            rc = gpu_matrix_create(ctx, out->level, rhs->rows, cw, rhs->format, &slice);
-            if (!rc) rc = gpu_matrix_copy_block(slice, rhs, 0, 0, 0, c0, rhs->rows, cw);
-        }
-        if (!rc) rc = gpu_matrix_create(ctx, out->level, rhs->rows * k, cw, GPU_POLY_FORMAT_EVAL, &dec);
-        if (!rc) rc = gpu_matrix_decompose_base(whole ? rhs : slice, base_bits, dec);
-        if (!rc && !whole) rc = gpu_matrix_create(ctx, out->level, lhs->rows, cw, GPU_POLY_FORMAT_EVAL, &prod);
-        if (!rc) rc = gpu_matrix_mul(whole ? out : prod, lhs, dec);
-        if (!rc && !whole) rc = gpu_matrix_copy_block(out, prod, 0, c0, 0, 0, lhs->rows, cw);
-        gpu_matrix_destroy(slice);
-        gpu_matrix_destroy(dec);
-        gpu_matrix_destroy(prod);
-        if (rc) return rc;
-    }
-    out->format = GPU_POLY_FORMAT_EVAL;
-    return 0;
+    return mul_tensor_identity_impl(out, lhs, rhs, 1, 1, base_bits, "gpupoly_matrix_mul_decompose");
+    ABI_GUARD_END
+}
+
+extern "C" int gpupoly_matrix_mul_decompose_small(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs,
+                                                  uint32_t base_bits) {
+    ABI_GUARD_BEGIN
+    return mul_tensor_identity_impl(out, lhs, rhs, 1, 2, base_bits, "gpupoly_matrix_mul_decompose_small");
+    ABI_GUARD_END
+}
+
+extern "C" int gpupoly_matrix_mul_tensor_identity(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs,
+                                                  size_t identity_size) {
+    ABI_GUARD_BEGIN
+    return mul_tensor_identity_impl(out, lhs, rhs, identity_size, 0, 0, "gpupoly_matrix_mul_tensor_identity");
+    ABI_GUARD_END
+}
+
+extern "C" int gpupoly_matrix_mul_tensor_identity_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs,
+                                                            size_t identity_size, uint32_t base_bits) {
+    ABI_GUARD_BEGIN
+    return mul_tensor_identity_impl(out, lhs, rhs, identity_size, 1, base_bits, "gpupoly_matrix_mul_tensor_identity_decompose");
     ABI_GUARD_END
 }
 

@@ -616,7 +616,15 @@ class GpuDCRTPolyMatrix:
         return out
 
     def mul_tensor_identity(self, other, identity_size) -> "GpuDCRTPolyMatrix":
+        """self * (I (x) other) (gpu_dcrt_poly.rs:1374-1390): one extension call, products written in place."""
         assert self.ncol == other.nrow * identity_size
+        if not mul_decompose_column_chunk_width_is_set():
+            out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, other.ncol * identity_size)
+            if self.nrow == 0 or out.ncol == 0:
+                return out
+            st = _ffi.lib().gpupoly_matrix_mul_tensor_identity(out.raw, self.ensure_eval().raw, other.ensure_eval().raw, identity_size)
+            check_status(st, "gpupoly_matrix_mul_tensor_identity")
+            return out
         w = other.nrow
         slices = [self.slice(0, self.nrow, i * w, (i + 1) * w)._mul_internal(other) for i in range(identity_size)]
         return slices[0].concat_columns(slices[1:])
@@ -625,8 +633,19 @@ class GpuDCRTPolyMatrix:
         return self.slice(0, self.nrow, j, j + 1).decompose_owned()
 
     def mul_tensor_identity_decompose(self, other, identity_size) -> "GpuDCRTPolyMatrix":
+        """self * (I (x) G^-1(other)) (gpu_dcrt_poly.rs:1392-1412).  The extension builds G^-1(other) once for all
+        identity blocks; the reference's per-block, per-column loop runs when its chunk switch is set."""
         k = self.params.modulus_digits()
         assert self.ncol == other.nrow * identity_size * k
+        if not mul_decompose_column_chunk_width_is_set():
+            out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, other.ncol * identity_size)
+            if self.nrow == 0 or out.ncol == 0:
+                return out
+            st = _ffi.lib().gpupoly_matrix_mul_tensor_identity_decompose(
+                out.raw, self.ensure_eval().raw, other.raw, identity_size, self.params.base_bits()
+            )
+            check_status(st, "gpupoly_matrix_mul_tensor_identity_decompose")
+            return out
         w = other.nrow * k
         outs = []
         for i in range(identity_size):
@@ -645,8 +664,8 @@ class GpuDCRTPolyMatrix:
         if self.nrow == 0 or ncol == 0:
             return out
         if not mul_decompose_column_chunk_width_is_set():
-            # one ABI call: digits generated inside the forward transform, transforms and product overlapped on two
-            # streams, S read once (gpupoly_matrix_mul_decompose).  The reference's column-chunk loop below (chunk
+            # one ABI call: digits generated inside the forward transform, all columns at once, S read once
+            # (gpupoly_matrix_mul_decompose).  The reference's column-chunk loop below (chunk
             # width 1 by default, re-reading S per chunk) runs only when its env switch is set explicitly.
             lhs = self.ensure_eval()
             st = _ffi.lib().gpupoly_matrix_mul_decompose(out.raw, lhs.raw, other.raw, self.params.base_bits())
@@ -666,6 +685,10 @@ class GpuDCRTPolyMatrix:
         ncol = other.ncol
         out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, ncol)
         if self.nrow == 0 or ncol == 0:
+            return out
+        if not mul_decompose_column_chunk_width_is_set():
+            st = _ffi.lib().gpupoly_matrix_mul_decompose_small(out.raw, self.ensure_eval().raw, other.raw, self.params.base_bits())
+            check_status(st, "gpupoly_matrix_mul_decompose_small")
             return out
         width = min(mul_decompose_column_chunk_width(), ncol)
         for c0 in range(0, ncol, width):

@@ -323,3 +323,26 @@ def test_transpose_one_launch(gpu, oracle, n, depth, bits, shape):
         assert t.size() == (shape[1], shape[0]) and t.is_ntt == fmt
         assert np.array_equal(t.to_rns(), a.transpose(1, 0, 2, 3))
         assert t.transpose() == ga
+
+
+@pytest.mark.parametrize("n,depth,bits,base,rows", [(64, 3, 17, 5, 1), (64, 3, 17, 5, 3), (32, 2, 51, 17, 1), (16384, 2, 24, 12, 1), (16384, 2, 24, 12, 2)])
+def test_tensor_identity_extensions_equal_the_wrapper_loops(gpu, oracle, hip_env, n, depth, bits, base, rows):
+    """gpupoly_matrix_mul_tensor_identity / _mul_tensor_identity_decompose / _mul_decompose_small against the
+    reference's own loops (slice, per-column decompose, product, concat: gpu_dcrt_poly.rs:1374-1412,1495-1574), which
+    the wrappers still run when MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH is set; row vectors take the in-place view path,
+    taller operands the slice-buffer path."""
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    k = p.modulus_digits()
+    ks = -(-bits // base)
+    ident, rows_b, cols_b = 3, 2, 3
+    B = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 301, rows_b, cols_b, moduli, n), True)
+    S = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 302, rows, rows_b * ident, moduli, n), True)
+    Sd = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 303, rows, rows_b * k * ident, moduli, n), True)
+    Ss = gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 304, rows, rows_b * ks, moduli, n), True)
+    got = (S.mul_tensor_identity(B, ident), Sd.mul_tensor_identity_decompose(B, ident), Ss.mul_decompose_small(B))
+    hip_env.set("MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH", "2")
+    want = (S.mul_tensor_identity(B, ident), Sd.mul_tensor_identity_decompose(B, ident), Ss.mul_decompose_small(B))
+    for g, w_ in zip(got, want):
+        assert g.size() == w_.size() and g.is_ntt and g == w_
+    assert got[0].size() == (rows, cols_b * ident)

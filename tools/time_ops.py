@@ -32,3 +32,26 @@ if which == "dec":
     print("gpupoly_matrix_mul_decompose (C ABI, one call): %.2f ms" % timed(ctx, lambda: _ffi.check_status(_ffi.lib().gpupoly_matrix_mul_decompose(out2.raw, S.raw, M.raw, 12), "mul_decompose"), 2))
     D = M.decompose()
     print("product (8x%d)*(%dx64) alone: %.2f ms" % (64 * k, 64 * k, timed(ctx, lambda: S * D, 2)))
+if which == "tensor":
+    # S (1 x rows_b*k*ident) * (I_ident (x) G^-1(B)), B rows_b x cols_b: a BGG-style row-vector evaluation step
+    p = mx.GpuDCRTPolyParams(n, mx.gen_crt_basis(n, 8, 24), 12)
+    us = mx.GpuDCRTPolyUniformSampler()
+    ctx = p.ctx()
+    k = p.modulus_digits()
+    rows_b, cols_b, ident = 4, 16, 4
+    B = us.sample_uniform(p, rows_b, cols_b, mx.DistType.FinRingDist())
+    S = us.sample_uniform(p, 1, rows_b * k * ident, mx.DistType.FinRingDist())
+    S0 = us.sample_uniform(p, 1, rows_b * ident, mx.DistType.FinRingDist())
+    os.environ.pop("MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH", None)
+    print("mul_tensor_identity_decompose (1 x %d) * (I_%d (x) G^-1(%dx%d)), extension: %.2f ms" % (S.ncol, ident, rows_b, cols_b, timed(ctx, lambda: S.mul_tensor_identity_decompose(B, ident))))
+    print("mul_tensor_identity (1 x %d) * (I_%d (x) %dx%d), extension: %.3f ms" % (S0.ncol, ident, rows_b, cols_b, timed(ctx, lambda: S0.mul_tensor_identity(B, ident))))
+    os.environ["MXX_MUL_DECOMPOSE_COLUMN_CHUNK_WIDTH"] = "1"
+    print("mul_tensor_identity_decompose, the reference wrapper's loop: %.2f ms" % timed(ctx, lambda: S.mul_tensor_identity_decompose(B, ident), 2))
+    print("mul_tensor_identity, the reference wrapper's loop: %.3f ms" % timed(ctx, lambda: S0.mul_tensor_identity(B, ident), 2))
+    key = bytes(range(32))
+    hs = mx.GpuDCRTPolyHashSampler()
+    d = mx.DistType.FinRingDist()
+    print("sample_hash_decomposed 8x8 (extension): %.2f ms" % timed(ctx, lambda: hs.sample_hash_decomposed(p, key, b"t", 8, 8, d)))
+    print("sample_hash(...).decompose() 8x8 (two calls): %.2f ms" % timed(ctx, lambda: hs.sample_hash(p, key, b"t", 8, 8, d).decompose()))
+    M = us.sample_uniform(p, 30, 120, d)
+    print("transpose 30x120: %.3f ms" % timed(ctx, lambda: M.transpose()))
