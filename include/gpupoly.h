@@ -166,6 +166,14 @@ int gpupoly_matrix_mul_scalar_intt(GpuMatrix *out, const GpuMatrix *lhs, const G
 /* out = src^T in one launch (the reference's wrapper issues rows*cols single-polynomial copy_block calls,
  * src/matrix/gpu_dcrt_poly.rs:1190-1199).                                                                */
 int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src);
+/* Constants written on the device instead of uploaded as full-size host byte vectors
+ * (src/matrix/gpu_dcrt_poly.rs:343-365 `new_zero_with_state`, :1158-1188 `identity`).  fill_zero keeps the format
+ * tag; fill_identity puts scalar_1x1 (EVAL; NULL = the constant 1) on the diagonal and tags the result EVAL.  */
+/* out = lhs (x) rhs (Kronecker product, all EVAL) in one launch; the reference's wrapper runs an entry slice, a
+ * mul_scalar and a copy_block per entry of lhs (src/matrix/gpu_dcrt_poly.rs:1225-1252).                     */
+int gpupoly_matrix_tensor(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
+int gpupoly_matrix_fill_zero(GpuMatrix *out);
+int gpupoly_matrix_fill_identity(GpuMatrix *out, const GpuMatrix *scalar_1x1);
 /* G^-1 of a freshly sampled rows x cols matrix: out is (rows*k) x cols, k = digits per entry (small != 0: the digits
  * of limb 0 only).  Same samples as gpu_matrix_sample_distribution, same digits as gpu_matrix_decompose_base(_small);
  * the sample's NTT and the decomposition's copy + INTT are skipped (replaces the pairs in

@@ -99,6 +99,9 @@ SIGNATURES = {
     "gpupoly_matrix_mul_tensor_identity_decompose": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32]),
     "gpupoly_matrix_mul_scalar_intt": (C.c_int, [_vp, _vp, _vp]),
     "gpupoly_matrix_transpose": (C.c_int, [_vp, _vp]),
+    "gpupoly_matrix_tensor": (C.c_int, [_vp, _vp, _vp]),
+    "gpupoly_matrix_fill_zero": (C.c_int, [_vp]),
+    "gpupoly_matrix_fill_identity": (C.c_int, [_vp, _vp]),
     "gpupoly_matrix_sample_decomposed": (C.c_int, [_vp, C.c_int, C.c_double, GpuRngSeed, C.c_uint32, C.c_int]),
     "gpupoly_timer_start": (C.c_int, [_vp]),
     "gpupoly_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),

@@ -53,6 +53,40 @@ __global__ void elementwise_kernel(W *__restrict__ out, const W *__restrict__ a,
     }
 }
 
+// Kronecker product of two EVAL matrices: out[(i*rb + r), (j*cb + c)] = a[i][j] o b[r][c], one launch
+// (blockIdx.y/z = output polynomial, blockIdx.x strides its residues 16 bytes per lane)
+template <typename W, int VN>
+__global__ void tensor_kernel(W *__restrict__ out, const W *__restrict__ a, const W *__restrict__ b,
+                              const LimbConst *__restrict__ limbs, uint32_t logN, size_t words_per_poly, size_t ca,
+                              size_t rb, size_t cb, size_t out_polys) {
+    const size_t o = static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y;
+    if (o >= out_polys) return;
+    const size_t out_cols = ca * cb;
+    const size_t R = o / out_cols, C = o - R * out_cols;
+    const size_t i = R / rb, r = R - i * rb, j = C / cb, c = C - j * cb;
+    const W *pa = a + (i * ca + j) * words_per_poly;
+    const W *pb = b + (r * cb + c) * words_per_poly;
+    W *po = out + o * words_per_poly;
+    typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
+    for (size_t w0 = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * VN; w0 < words_per_poly;
+         w0 += static_cast<size_t>(gridDim.x) * blockDim.x * VN) {
+        const LimbConst lc = limbs[w0 >> logN];
+        const W q = static_cast<W>(lc.q);
+        W av[VN], bv[VN], ov[VN];
+        if (VN == 1) {
+            av[0] = pa[w0];
+            bv[0] = pb[w0];
+        } else {
+            *reinterpret_cast<V16 *>(av) = *reinterpret_cast<const V16 *>(pa + w0);
+            *reinterpret_cast<V16 *>(bv) = *reinterpret_cast<const V16 *>(pb + w0);
+        }
+#pragma unroll
+        for (int t = 0; t < VN; ++t) ov[t] = mul_mod<W>(av[t], bv[t], q, lc.mu, lc.kbits);
+        if (VN == 1) po[w0] = ov[0];
+        else *reinterpret_cast<V16 *>(po + w0) = *reinterpret_cast<const V16 *>(ov);
+    }
+}
+
 template <typename W>
 __global__ void equal_kernel(const W *__restrict__ a, const W *__restrict__ b, size_t total, int *__restrict__ diff) {
     size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -488,6 +522,48 @@ extern "C" int gpu_matrix_mul_scalar(GpuMatrix *out, const GpuMatrix *lhs, const
     if (rc) return rc;
     out->format = GPU_POLY_FORMAT_EVAL;
     return 0;
+    ABI_GUARD_END
+}
+
+template <typename W>
+static int launch_tensor_typed(GpuMatrix *out, const GpuMatrix *a, const GpuMatrix *b) {
+    GpuContext *ctx = out->ctx;
+    constexpr int VNATIVE = 16 / sizeof(W);
+    const size_t wpp = matrix_limbs(out) * static_cast<size_t>(ctx->N);
+    const size_t polys = matrix_polys(out);
+    const size_t gy = std::min<size_t>(polys, 65535), gz = (polys + gy - 1) / gy;
+    if (gz > 65535) return set_error("gpupoly_matrix_tensor: matrix too large");
+    if (ctx->N >= VNATIVE) {
+        const dim3 grid(static_cast<unsigned>(std::min<size_t>((wpp / VNATIVE + 255) / 256, 64)), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
+        hipLaunchKernelGGL((tensor_kernel<W, VNATIVE>), grid, dim3(256), 0, ctx->stream, static_cast<W *>(out->data),
+                           static_cast<const W *>(a->data), static_cast<const W *>(b->data), ctx->d_limbs, ctx->logN, wpp,
+                           a->cols, b->rows, b->cols, polys);
+    } else {
+        const dim3 grid(static_cast<unsigned>(std::min<size_t>((wpp + 255) / 256, 64)), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
+        hipLaunchKernelGGL((tensor_kernel<W, 1>), grid, dim3(256), 0, ctx->stream, static_cast<W *>(out->data),
+                           static_cast<const W *>(a->data), static_cast<const W *>(b->data), ctx->d_limbs, ctx->logN, wpp,
+                           a->cols, b->rows, b->cols, polys);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Extension: a (x) b in one launch.  The reference's wrapper runs, per entry of a, an entry slice, a mul_scalar into
+// a temporary and a copy_block (src/matrix/gpu_dcrt_poly.rs:1225-1252): 3 launches and two extra passes over b.
+extern "C" int gpupoly_matrix_tensor(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    ABI_GUARD_BEGIN
+    if (!out || !lhs || !rhs) return set_error("gpupoly_matrix_tensor: null matrix");
+    if (out->ctx != lhs->ctx || out->ctx != rhs->ctx) return set_error("gpupoly_matrix_tensor: context mismatch");
+    if (out->level != lhs->level || out->level != rhs->level) return set_error("gpupoly_matrix_tensor: level mismatch");
+    if (out->rows != lhs->rows * rhs->rows || out->cols != lhs->cols * rhs->cols)
+        return set_error("gpupoly_matrix_tensor: shape mismatch");
+    if (lhs->format != GPU_POLY_FORMAT_EVAL || rhs->format != GPU_POLY_FORMAT_EVAL)
+        return set_error("gpupoly_matrix_tensor requires Eval format");
+    if (out == lhs || out == rhs) return set_error("gpupoly_matrix_tensor: output must not alias an input");
+    out->format = GPU_POLY_FORMAT_EVAL;
+    if (matrix_polys(out) == 0) return 0;
+    if (ctx_activate(out->ctx)) return 1;
+    return out->ctx->wide ? launch_tensor_typed<uint64_t>(out, lhs, rhs) : launch_tensor_typed<uint32_t>(out, lhs, rhs);
     ABI_GUARD_END
 }
 

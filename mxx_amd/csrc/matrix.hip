@@ -294,6 +294,59 @@ extern "C" int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src) {
     ABI_GUARD_END
 }
 
+// ---- constant matrices written on the device (extensions) ----------------------------------------
+// The reference's wrapper builds zero and identity matrices as host byte vectors of the full size (8 bytes per
+// residue) and uploads them (src/matrix/gpu_dcrt_poly.rs:343-365 `new_zero_with_state`, :1158-1188 `identity`):
+// a PCIe transfer of the whole matrix for a constant.  Here: one memset, plus one small kernel for the diagonal.
+extern "C" int gpupoly_matrix_fill_zero(GpuMatrix *out) {
+    ABI_GUARD_BEGIN
+    if (!out) return set_error("gpupoly_matrix_fill_zero: null matrix");
+    if (out->bytes == 0) return 0;
+    if (ctx_activate(out->ctx)) return 1;
+    HIP_TRY(hipMemsetAsync(out->data, 0, out->bytes, out->ctx->stream));
+    return 0;
+    ABI_GUARD_END
+}
+
+template <typename W>
+__global__ void fill_diagonal_kernel(W *__restrict__ out, const W *__restrict__ scalar, size_t size, size_t words_per_poly) {
+    const size_t d = blockIdx.y;
+    W *dst = out + (d * size + d) * words_per_poly;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < words_per_poly;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        dst[i] = scalar ? scalar[i] : static_cast<W>(1);  // EVAL form of the constant 1: every slot is 1
+}
+
+extern "C" int gpupoly_matrix_fill_identity(GpuMatrix *out, const GpuMatrix *scalar) {
+    ABI_GUARD_BEGIN
+    if (!out) return set_error("gpupoly_matrix_fill_identity: null matrix");
+    if (out->rows != out->cols) return set_error("gpupoly_matrix_fill_identity: matrix must be square");
+    if (scalar) {
+        if (scalar->ctx != out->ctx || scalar->level != out->level)
+            return set_error("gpupoly_matrix_fill_identity: context/level mismatch");
+        if (scalar->rows != 1 || scalar->cols != 1) return set_error("gpupoly_matrix_fill_identity: scalar must be 1x1");
+        if (scalar->format != GPU_POLY_FORMAT_EVAL) return set_error("gpupoly_matrix_fill_identity requires an Eval scalar");
+        if (scalar == out) return set_error("gpupoly_matrix_fill_identity: output must not alias the scalar");
+    }
+    out->format = GPU_POLY_FORMAT_EVAL;
+    if (out->bytes == 0) return 0;
+    GpuContext *ctx = out->ctx;
+    if (ctx_activate(ctx)) return 1;
+    if (out->rows > 65535) return set_error("gpupoly_matrix_fill_identity: matrix too large");
+    HIP_TRY(hipMemsetAsync(out->data, 0, out->bytes, ctx->stream));
+    const size_t words = matrix_limbs(out) * static_cast<size_t>(ctx->N);
+    const dim3 grid(static_cast<unsigned>(std::min<size_t>((words + 255) / 256, 256)), static_cast<unsigned>(out->rows));
+    if (ctx->wide)
+        hipLaunchKernelGGL(fill_diagonal_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, static_cast<uint64_t *>(out->data),
+                           scalar ? static_cast<const uint64_t *>(scalar->data) : nullptr, out->rows, words);
+    else
+        hipLaunchKernelGGL(fill_diagonal_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, static_cast<uint32_t *>(out->data),
+                           scalar ? static_cast<const uint32_t *>(scalar->data) : nullptr, out->rows, words);
+    HIP_TRY(hipGetLastError());
+    return 0;
+    ABI_GUARD_END
+}
+
 extern "C" int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, size_t *out_bytes) {
     if (!mat || !out_ptr || !out_bytes) return set_error("gpupoly_matrix_device_ptr: null argument");
     *out_ptr = mat->data;

@@ -90,8 +90,8 @@ class GpuDCRTPolyMatrix:
         out = cls(params, nrow, ncol, level, is_ntt)
         if nrow == 0 or ncol == 0:
             return out
-        n = params.ring_dimension()
-        out.load_rns(np.zeros((nrow, ncol, level + 1, n), dtype=np.uint64), is_ntt)
+        # the reference uploads a host vector of zeros (gpu_dcrt_poly.rs:343-365); one device memset here
+        check_status(_ffi.lib().gpupoly_matrix_fill_zero(out.raw), "gpupoly_matrix_fill_zero")
         return out
 
     @classmethod
@@ -112,17 +112,17 @@ class GpuDCRTPolyMatrix:
 
     @classmethod
     def identity(cls, params, size, scalar=None) -> "GpuDCRTPolyMatrix":
-        n, L = params.ring_dimension(), params.crt_depth()
-        host = np.zeros((size, size, L, n), dtype=np.uint64)
-        if size:
-            if scalar is None:
-                diag = np.ones((L, n), dtype=np.uint64)  # EVAL form of the constant 1
-            else:
-                sm = scalar.inner if hasattr(scalar, "inner") else scalar
-                diag = sm.ensure_eval().to_rns()[0, 0]
-            for i in range(size):
-                host[i, i] = diag
-        return cls.from_rns(params, host, True)
+        """`identity` (gpu_dcrt_poly.rs:1158-1188); built on the device (gpupoly_matrix_fill_identity)."""
+        out = cls.new_empty(params, size, size)
+        if size == 0:
+            return out
+        s_raw = None
+        if scalar is not None:
+            sm = scalar.inner if hasattr(scalar, "inner") else scalar
+            sm = sm.ensure_eval()
+            s_raw = sm.raw
+        check_status(_ffi.lib().gpupoly_matrix_fill_identity(out.raw, s_raw), "gpupoly_matrix_fill_identity")
+        return out
 
     @classmethod
     def gadget_matrix(cls, params, size) -> "GpuDCRTPolyMatrix":
@@ -468,14 +468,16 @@ class GpuDCRTPolyMatrix:
         return out
 
     def tensor(self, other) -> "GpuDCRTPolyMatrix":
+        """Kronecker product (gpu_dcrt_poly.rs:1225-1252: entry, mul_scalar, copy_block per entry there); one launch
+        here.  As in the reference the blocks come out of mul_scalar, i.e. the result is EVAL."""
         assert self.params == other.params and self.level == other.level and self.is_ntt == other.is_ntt
         out = GpuDCRTPolyMatrix(self.params, self.nrow * other.nrow, self.ncol * other.ncol, self.level, self.is_ntt)
         if 0 in (self.nrow, self.ncol, other.nrow, other.ncol):
             return out
-        for i in range(self.nrow):
-            for j in range(self.ncol):
-                block = other.mul_scalar(self.entry(i, j))
-                out.copy_block_from(block, i * other.nrow, j * other.ncol, 0, 0, other.nrow, other.ncol)
+        lhs, rhs = self.ensure_eval(), other.ensure_eval()
+        st = _ffi.lib().gpupoly_matrix_tensor(out.raw, lhs.raw, rhs.raw)
+        check_status(st, "gpupoly_matrix_tensor")
+        out.is_ntt = True
         return out
 
     def vectorize_columns(self) -> "GpuDCRTPolyMatrix":
@@ -622,7 +624,8 @@ class GpuDCRTPolyMatrix:
             out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, other.ncol * identity_size)
             if self.nrow == 0 or out.ncol == 0:
                 return out
-            st = _ffi.lib().gpupoly_matrix_mul_tensor_identity(out.raw, self.ensure_eval().raw, other.ensure_eval().raw, identity_size)
+            lhs, rhs = self.ensure_eval(), other.ensure_eval()  # held: a converted copy must outlive the call
+            st = _ffi.lib().gpupoly_matrix_mul_tensor_identity(out.raw, lhs.raw, rhs.raw, identity_size)
             check_status(st, "gpupoly_matrix_mul_tensor_identity")
             return out
         w = other.nrow
@@ -641,8 +644,9 @@ class GpuDCRTPolyMatrix:
             out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow, other.ncol * identity_size)
             if self.nrow == 0 or out.ncol == 0:
                 return out
+            lhs = self.ensure_eval()
             st = _ffi.lib().gpupoly_matrix_mul_tensor_identity_decompose(
-                out.raw, self.ensure_eval().raw, other.raw, identity_size, self.params.base_bits()
+                out.raw, lhs.raw, other.raw, identity_size, self.params.base_bits()
             )
             check_status(st, "gpupoly_matrix_mul_tensor_identity_decompose")
             return out
@@ -687,7 +691,8 @@ class GpuDCRTPolyMatrix:
         if self.nrow == 0 or ncol == 0:
             return out
         if not mul_decompose_column_chunk_width_is_set():
-            st = _ffi.lib().gpupoly_matrix_mul_decompose_small(out.raw, self.ensure_eval().raw, other.raw, self.params.base_bits())
+            lhs = self.ensure_eval()
+            st = _ffi.lib().gpupoly_matrix_mul_decompose_small(out.raw, lhs.raw, other.raw, self.params.base_bits())
             check_status(st, "gpupoly_matrix_mul_decompose_small")
             return out
         width = min(mul_decompose_column_chunk_width(), ncol)

@@ -346,3 +346,42 @@ def test_tensor_identity_extensions_equal_the_wrapper_loops(gpu, oracle, hip_env
     for g, w_ in zip(got, want):
         assert g.size() == w_.size() and g.is_ntt and g == w_
     assert got[0].size() == (rows, cols_b * ident)
+
+
+@pytest.mark.parametrize("n,depth,bits", [(4, 2, 17), (128, 3, 24), (64, 2, 51), (16384, 2, 24)])
+def test_device_side_constants_and_kronecker_product(gpu, oracle, n, depth, bits):
+    """gpupoly_matrix_fill_zero / _fill_identity / _tensor against the host-built matrices the reference's wrappers
+    upload (gpu_dcrt_poly.rs:343-365, 1158-1188) and the per-entry mul_scalar loop (:1225-1252)."""
+    p = make_params(gpu, oracle, n, depth, bits, 4)
+    moduli = p.moduli()
+    L = len(moduli)
+    for coeff_tag in (True, False):
+        z = gpu.GpuDCRTPolyMatrix._new_zero_with_state(p, 3, 2, L - 1, coeff_tag)
+        assert z.is_ntt == coeff_tag and z.size() == (3, 2) and not z.to_rns().any()
+    ident = gpu.GpuDCRTPolyMatrix.identity(p, 3)
+    want = np.zeros((3, 3, L, n), dtype=np.uint64)
+    for i in range(3):
+        want[i, i] = 1
+    assert ident.is_ntt and np.array_equal(ident.to_rns(), want)
+    s = rand_matrix(oracle, 410, 1, 1, moduli, n)
+    gs = gpu.GpuDCRTPolyMatrix.from_rns(p, s, False)  # coefficient-domain scalar: identity() transforms it first
+    scaled = gpu.GpuDCRTPolyMatrix.identity(p, 2, gpu.GpuDCRTPoly(gs))
+    s_eval = oracle.matrix_ntt(s, moduli)
+    want2 = np.zeros((2, 2, L, n), dtype=np.uint64)
+    want2[0, 0] = want2[1, 1] = s_eval[0, 0]
+    assert np.array_equal(scaled.to_rns(), want2)
+    assert gpu.GpuDCRTPolyMatrix.identity(p, 0).size() == (0, 0)
+    # Kronecker product: out[(i*rb + r), (j*cb + c)] = a[i][j] * b[r][c]
+    a = oracle.matrix_ntt(rand_matrix(oracle, 411, 2, 3, moduli, n), moduli)
+    b = oracle.matrix_ntt(rand_matrix(oracle, 412, 3, 2, moduli, n), moduli)
+    t = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True).tensor(gpu.GpuDCRTPolyMatrix.from_rns(p, b, True))
+    assert t.size() == (6, 6) and t.is_ntt
+    got = t.to_rns()
+    for i in range(2):
+        for j in range(3):
+            blk = oracle.pointwise("mul", np.broadcast_to(a[i, j], b.shape).copy(), b, moduli)
+            assert np.array_equal(got[i * 3 : (i + 1) * 3, j * 2 : (j + 1) * 2], blk)
+    # coefficient-domain operands: the wrapper transforms them, the result is the EVAL product (as in the reference)
+    ac = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True).into_coeff_domain()
+    bc = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True).into_coeff_domain()
+    assert ac.tensor(bc) == t
