@@ -172,6 +172,10 @@ int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src);
 /* out = lhs (x) rhs (Kronecker product, all EVAL) in one launch; the reference's wrapper runs an entry slice, a
  * mul_scalar and a copy_block per entry of lhs (src/matrix/gpu_dcrt_poly.rs:1225-1252).                     */
 int gpupoly_matrix_tensor(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
+/* out[dst_row .. dst_row + lhs.rows) = lhs + rhs: the sum lands in a row block of a taller matrix (contiguous in
+ * the row-major layout) instead of a copy_block followed by an add_block; used by the preimage's final assembly
+ * (src/sampler/trapdoor/gpu.rs:340-369).  The whole destination takes the operands' format tag.            */
+int gpupoly_matrix_add_rows(GpuMatrix *out, size_t dst_row, const GpuMatrix *lhs, const GpuMatrix *rhs);
 int gpupoly_matrix_fill_zero(GpuMatrix *out);
 int gpupoly_matrix_fill_identity(GpuMatrix *out, const GpuMatrix *scalar_1x1);
 /* G^-1 of a freshly sampled rows x cols matrix: out is (rows*k) x cols, k = digits per entry (small != 0: the digits

@@ -484,6 +484,41 @@ static int launch_elementwise(GpuMatrix *out, const GpuMatrix *a, const GpuMatri
 }
 
 // ---- ABI ---------------------------------------------------------------------------------------
+// a window of whole polynomials of `m`, row-major from polynomial `first_poly`, seen as a rows x cols matrix
+static GpuMatrix matrix_view(const GpuMatrix *m, size_t first_poly, size_t rows, size_t cols, size_t poly_bytes) {
+    GpuMatrix v;
+    v.ctx = m->ctx;
+    v.level = m->level;
+    v.rows = rows;
+    v.cols = cols;
+    v.format = m->format;
+    v.data = static_cast<char *>(m->data) + first_poly * poly_bytes;
+    v.bytes = rows * cols * poly_bytes;
+    return v;
+}
+
+// Extension: out[dst_row .. dst_row + lhs.rows) = lhs + rhs, written straight into a row block of a taller matrix
+// (row blocks are contiguous in the row-major layout).  The preimage's x = [p1 + [R;E] z ; p2 + z] otherwise takes
+// a copy_block of p and an add_block of the product per part (src/sampler/trapdoor/gpu.rs:340-369): five passes
+// over the largest operands instead of three.
+extern "C" int gpupoly_matrix_add_rows(GpuMatrix *out, size_t dst_row, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    ABI_GUARD_BEGIN
+    if (!out || !lhs || !rhs) return set_error("gpupoly_matrix_add_rows: null matrix");
+    if (matrix_check_same_shape(lhs, rhs, "gpupoly_matrix_add_rows")) return 1;
+    if (out->ctx != lhs->ctx || out->level != lhs->level) return set_error("gpupoly_matrix_add_rows: context/level mismatch");
+    if (out->cols != lhs->cols || dst_row > out->rows || lhs->rows > out->rows - dst_row)
+        return set_error("gpupoly_matrix_add_rows: row block out of range");
+    if (lhs->format != rhs->format) return set_error("gpupoly_matrix_add_rows: operands must share a format");
+    if (out == lhs || out == rhs) return set_error("gpupoly_matrix_add_rows: output must not alias an input");
+    const size_t poly_bytes = matrix_limbs(out) * static_cast<size_t>(out->ctx->N) * out->ctx->word_bytes;
+    GpuMatrix view = matrix_view(out, dst_row * out->cols, lhs->rows, lhs->cols, poly_bytes);
+    int rc = launch_elementwise<OP_ADD, false>(&view, lhs, rhs);
+    if (rc) return rc;
+    out->format = lhs->format;  // the whole destination takes the source's tag, as copy_block / add_block do
+    return 0;
+    ABI_GUARD_END
+}
+
 extern "C" int gpu_matrix_add(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
     ABI_GUARD_BEGIN
     if (matrix_check_same_shape(out, lhs, "gpu_matrix_add") || matrix_check_same_shape(lhs, rhs, "gpu_matrix_add"))
@@ -592,18 +627,6 @@ extern "C" int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
 // X is built once per column chunk and used for every identity block: the reference's wrappers recompute the
 // decomposition of every column for every block (src/matrix/gpu_dcrt_poly.rs:1392-1412).  Row-vector operands
 // (one row: BGG encodings) are multiplied in place through views; taller ones go through one reused slice buffer.
-static GpuMatrix matrix_view(const GpuMatrix *m, size_t first_poly, size_t rows, size_t cols, size_t poly_bytes) {
-    GpuMatrix v;
-    v.ctx = m->ctx;
-    v.level = m->level;
-    v.rows = rows;
-    v.cols = cols;
-    v.format = m->format;
-    v.data = static_cast<char *>(m->data) + first_poly * poly_bytes;
-    v.bytes = rows * cols * poly_bytes;
-    return v;
-}
-
 static int mul_tensor_identity_impl(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, size_t identity_size,
                                     int mode, uint32_t base_bits, const char *who) {
     if (!out || !lhs || !rhs) return set_error(std::string(who) + ": null matrix");

@@ -385,6 +385,14 @@ class GpuDCRTPolyMatrix:
         check_status(st, "gpu_matrix_add_block")
         self.is_ntt = src.is_ntt
 
+    def add_rows_from(self, dst_row, lhs, rhs) -> None:
+        """self[dst_row : dst_row + lhs.nrow] = lhs + rhs in one pass (gpupoly_matrix_add_rows)."""
+        assert lhs.size() == rhs.size() and lhs.ncol == self.ncol and dst_row + lhs.nrow <= self.nrow
+        if lhs.is_ntt != rhs.is_ntt:
+            rhs = rhs.ensure_eval() if lhs.is_ntt else rhs.ensure_coeff()
+        check_status(_ffi.lib().gpupoly_matrix_add_rows(self.raw, dst_row, lhs.raw, rhs.raw), "gpupoly_matrix_add_rows")
+        self.is_ntt = lhs.is_ntt
+
     def slice(self, row_start, row_end, col_start, col_end) -> "GpuDCRTPolyMatrix":
         nrow, ncol = row_end - row_start, col_end - col_start
         out = GpuDCRTPolyMatrix(self.params, nrow, ncol, self.level, self.is_ntt)

@@ -385,3 +385,23 @@ def test_device_side_constants_and_kronecker_product(gpu, oracle, n, depth, bits
     ac = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True).into_coeff_domain()
     bc = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True).into_coeff_domain()
     assert ac.tensor(bc) == t
+
+
+def test_add_rows_extension(gpu, oracle):
+    """gpupoly_matrix_add_rows: out[r0 : r0 + rows] = a + b lands in a row block of a taller matrix and leaves the
+    other rows alone (the preimage's final assembly uses it instead of copy_block + add_block)."""
+    from mxx_amd import _ffi
+
+    n = 256
+    p = make_params(gpu, oracle, n, 2, 24, 12)
+    moduli = p.moduli()
+    base = rand_matrix(oracle, 500, 5, 3, moduli, n)
+    a, b = rand_matrix(oracle, 501, 2, 3, moduli, n), rand_matrix(oracle, 502, 2, 3, moduli, n)
+    out = gpu.GpuDCRTPolyMatrix.from_rns(p, base, True)
+    out.add_rows_from(2, gpu.GpuDCRTPolyMatrix.from_rns(p, a, True), gpu.GpuDCRTPolyMatrix.from_rns(p, b, True))
+    want = base.copy()
+    want[2:4] = oracle.pointwise("add", a, b, moduli)
+    assert np.array_equal(out.to_rns(), want)
+    ga, gb = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True), gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    with pytest.raises(gpu.GpuPolyError):  # rows 4..5 of a 5-row matrix
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_add_rows(out.raw, 4, ga.raw, gb.raw), "gpupoly_matrix_add_rows")
