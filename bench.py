@@ -191,6 +191,8 @@ class Workload:
         self.word = self.ctx.word_bytes()
         self.device = device
         self.nmarks = len(self.kernels) + 1
+        self._pending = {}
+        self.full = None
 
     def moduli(self, mx):
         return mx.gen_crt_basis(N_RING, self.depth, 24)
@@ -210,6 +212,27 @@ class Workload:
 
     def check(self):
         pass
+
+    # -- sharded runs: the gather of step i runs under the compute of step i+1 (two buffer slots) ----------------
+    gather = None
+
+    def gather_begin(self, i):
+        """before step i writes buffer slot i % 2: the engine's stream waits for the gather that last used it"""
+        slot = i & 1
+        if self.gather is not None and self._pending.get(slot) is not None:
+            self.full = self.gather.finish(self._pending.pop(slot)[1])
+        return slot
+
+    def gather_enqueue(self, i, slot, local):
+        if self.gather is not None:
+            self._pending[slot] = (i, self.gather.start(local, slot))
+
+    def drain(self):
+        """finish every gather still in flight, oldest first (called before the clock stops)"""
+        if self.gather is not None:
+            for slot in sorted(self._pending, key=lambda s_: self._pending[s_][0]):
+                self.full = self.gather.finish(self._pending[slot][1])
+            self._pending.clear()
 
 
 class M1(Workload):
@@ -284,9 +307,10 @@ class MatMul(Workload):
             sr = shard_range(c, d.world, d.rank)
             self.c_local = len(sr)
             self.b = uniform_matrix(mx, p, k, self.c_local, 5, total_cols=c, col_start=sr.start)
-            self.gather = ColumnAllGather(p, r, c, L - 1, d.torch, d.dist, self.device)
+            self.gather = ColumnAllGather(p, r, c, L - 1, d.torch, d.dist, self.device, slots=2)
             self.sharding = (f"strong: B/C column blocks by shard_range ({c} -> {self.c_local} on this rank), "
-                             "A replicated, one RCCL all-gather of C's blocks per step")
+                             "A replicated, one RCCL all-gather of C's blocks per step, ordered on the device and "
+                             "overlapped with the next step's product (two buffer slots)")
             self.units_total = r * k * c  # the whole job's ring-ops per step
         else:
             self.c_local = c
@@ -294,7 +318,8 @@ class MatMul(Workload):
             self.gather = None
             self.sharding = "weak: every rank multiplies the full shape, no collective" if d.world > 1 else "single GPU"
             self.units_total = r * k * c * d.world
-        self.out = mx.GpuDCRTPolyMatrix(p, r, max(self.c_local, 1), L - 1, True)
+        self.outs = [mx.GpuDCRTPolyMatrix(p, r, max(self.c_local, 1), L - 1, True) for _ in range(2 if self.gather else 1)]
+        self.out = self.outs[0]
         self.units = self.units_total
         algo = float(r * k + k * self.c_local + r * self.c_local) * N_RING * L * self.word  # SURVEY 8d, this rank's launch
         self.kernels = ((self.kernel_label, algo),)
@@ -305,14 +330,15 @@ class MatMul(Workload):
     def step(self, i, mark):
         from mxx_amd import _ffi
 
+        slot = self.gather_begin(i)
+        self.out = self.outs[slot if self.gather else 0]
         if mark:
             self.mark(i, 0)
         if self.c_local:
             _ffi.check_status(_ffi.lib().gpu_matrix_mul(self.out.raw, self.a.raw, self.b.raw), "gpu_matrix_mul")
         if mark:
             self.mark(i, 1)
-        if self.gather is not None:
-            self.full = self.gather.gather(self.out if self.c_local else self.out.slice_columns(0, 0))
+        self.gather_enqueue(i, slot, self.out if self.c_local else self.out.slice_columns(0, 0))
 
     def check(self):
         """size-independent property on the timed operands: (A*B) == columns of A*[B] recomputed entry-wise
@@ -358,9 +384,10 @@ class Preimage(Workload):
             sr = shard_range(self.cols, d.world, d.rank)
             self.c_local = len(sr)
             self.target = uniform_matrix(mx, p, self.dsize, self.c_local, 9, total_cols=self.cols, col_start=sr.start)
-            self.gather = ColumnAllGather(p, (k + 2) * self.dsize, self.cols, self.depth - 1, d.torch, d.dist, self.device)
+            self.gather = ColumnAllGather(p, (k + 2) * self.dsize, self.cols, self.depth - 1, d.torch, d.dist, self.device, slots=2)
             self.sharding = (f"strong: {self.cols} target columns by shard_range ({self.c_local} on this rank), trapdoor "
-                             "replicated, one RCCL all-gather of the preimage blocks per call")
+                             "replicated, one RCCL all-gather of the preimage blocks per call, ordered on the device and "
+                             "overlapped with the next call")
             self.units = self.cols
         else:
             self.c_local = self.cols
@@ -375,6 +402,7 @@ class Preimage(Workload):
         self.x = None
 
     def step(self, i, mark):
+        slot = self.gather_begin(i)
         if mark:
             self.mark(i, 0)
         if self.c_local:
@@ -382,7 +410,9 @@ class Preimage(Workload):
         if mark:
             self.mark(i, 1)
         if self.gather is not None:
-            self.full = self.gather.gather(self.x)
+            if not self.c_local:
+                self.x = self.mx.GpuDCRTPolyMatrix(self.params, self.gather.rows, 0, self.depth - 1, True)
+            self.gather_enqueue(i, slot, self.x)
 
     def check(self):
         if self.c_local:
@@ -465,10 +495,12 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
             wl.mark(i, j)
     for i in range(warmup):
         wl.step(i, False)
+    wl.drain()
     d.barrier_sync(mx.gpu_device_sync)
     t0 = time.perf_counter()
     for i in range(steps):
         wl.step(i, True)
+    wl.drain()
     d.barrier_sync(mx.gpu_device_sync)
     elapsed = d.max_over_ranks(time.perf_counter() - t0)
     kernel_ms = wl.kernel_ms(steps)
@@ -478,6 +510,7 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
         t1 = time.perf_counter()
         for i in range(steps):
             wl.step(i, False)
+        wl.drain()
         d.barrier_sync(mx.gpu_device_sync)
         reps.append(d.max_over_ranks(time.perf_counter() - t1) * 1e3 / steps)
     wl.check()
@@ -558,6 +591,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))  # nothing GPU-related has been imported or called in this process
 
+    # stdout carries exactly ONE JSON line: native libraries write banners to file descriptor 1 (RCCL prints its
+    # version block there when a communicator is created), so everything else is sent to stderr from here on
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     d = Dist(args)
     if args.dry_run:
         ok = 1.0
@@ -566,7 +608,7 @@ def main():
             d.dist.all_reduce(t)
             ok = float(t.item())
         if d.rank == 0:
-            print(json.dumps({"dry_run": True, "world": d.world, "all_reduce": ok, "backend": d.backend if d.active else None}), flush=True)
+            emit({"dry_run": True, "world": d.world, "all_reduce": ok, "backend": d.backend if d.active else None})
         d.finish()
         return
     if d.active and d.world != args.gpus and d.rank == 0:
@@ -613,7 +655,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
     if d.rank == 0:
         line.setdefault("cpu_baseline", None)
-        print(json.dumps(line), flush=True)
+        emit(line)
     d.finish()
 
 

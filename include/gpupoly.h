@@ -199,6 +199,8 @@ int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, size_t *out_
 int gpupoly_matrix_copy_to_context(GpuContext *dst_ctx, const GpuMatrix *src, GpuMatrix **out);
 int gpupoly_context_device(const GpuContext *ctx, int *out_device);
 int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes);
+/* the context's compute stream (hipStream_t): lets the host order collectives against engine work on the device */
+int gpupoly_context_stream(const GpuContext *ctx, void **out_stream);
 const char *gpupoly_version(void);
 /* MXX_HIP_* switches are read once, at gpu_context_create; this re-reads them for every live
  * context of the process (tests flip them between calls).                      */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "gpupoly_matrix_copy_to_context": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "gpupoly_context_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_context_word_bytes": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gpupoly_context_stream": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "gpupoly_version": (C.c_char_p, []),
     "gpupoly_reload_env": (C.c_int, []),
 }

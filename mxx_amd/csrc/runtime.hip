@@ -455,6 +455,14 @@ extern "C" int gpupoly_context_device(const GpuContext *ctx, int *out_device) {
     return 0;
 }
 
+// the context's compute stream (a hipStream_t), so that a host framework can order its own work - e.g. an RCCL
+// collective on the engine's allocations - against the engine's on the device instead of through host syncs
+extern "C" int gpupoly_context_stream(const GpuContext *ctx, void **out_stream) {
+    if (!ctx || !out_stream) return set_error("gpupoly_context_stream: null argument");
+    *out_stream = static_cast<void *>(ctx->stream);
+    return 0;
+}
+
 extern "C" int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes) {
     if (!ctx || !out_bytes) return set_error("gpupoly_context_word_bytes: null argument");
     *out_bytes = ctx->word_bytes;

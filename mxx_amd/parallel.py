@@ -80,10 +80,11 @@ class DeviceBuffer:
     """Zero-copy view of a libgpupoly matrix as a torch tensor (`__cuda_array_interface__`),
     so RCCL collectives run directly on the engine's HBM allocation.
 
-    Ordering contract (the engine's stream is not torch's): the caller synchronises in BOTH
-    directions - the engine's work that produced the bytes must have completed before a collective
-    reads them (`gpu_device_sync()`), and the collective must have completed (e.g.
-    `torch.cuda.current_stream().synchronize()`) before any engine call writes, frees or re-uses
+    Ordering contract (the engine's stream is not torch's default stream): either issue the torch work under
+    `torch.cuda.stream(engine_stream(...))`, which orders it against the engine's kernels on the device (what
+    ColumnAllGather does), or synchronise on the host in BOTH directions - the engine's work that produced the
+    bytes must have completed before a collective reads them (`gpu_device_sync()`), and the collective must have
+    completed (e.g. `torch.cuda.current_stream().synchronize()`) before any engine call writes, frees or re-uses
     the viewed matrix.  The matrix is kept alive by this object; keep the object alive until then."""
 
     def __init__(self, matrix):
@@ -108,6 +109,12 @@ class DeviceBuffer:
         return torch.as_tensor(self, device=torch.device("cuda", device_index))
 
 
+def engine_stream(params, torch, device_index: int):
+    """The engine context's compute stream as a torch stream: work issued under `torch.cuda.stream(...)` of it - a
+    collective in particular - is ordered against the engine's kernels on the device, with no host synchronisation."""
+    return torch.cuda.ExternalStream(params.ctx().stream_handle(), device=torch.device("cuda", device_index))
+
+
 class ColumnAllGather:
     """All-gather of the column blocks of a rows x cols_total matrix that is sharded over the ranks by
     `shard_range` - the one exchange step of the sharded product / sharded preimage (SURVEY.md 8e;
@@ -116,9 +123,14 @@ class ColumnAllGather:
     RCCL reads and writes the engine's own HBM allocations (DeviceBuffer).  With one row and equal
     shards every rank's block is a contiguous run of the full matrix, which is then the receive
     buffer itself; otherwise blocks are padded to the largest shard, gathered into a staging matrix
-    and moved into place with copy_block."""
+    and moved into place with copy_block.
 
-    def __init__(self, params, rows: int, cols_total: int, level: int, torch, dist, device_index: int):
+    Ordering is on the device: the collective is issued with the engine's stream as torch's current stream, so it
+    starts after the kernels that produced the block and `finish` makes the engine's stream wait for it - the host
+    never blocks.  `start` / `finish` with `slots` > 1 let the gather of one step run under the compute of the next
+    (xGMI transfer and kernels overlap); `gather` is the two back to back."""
+
+    def __init__(self, params, rows: int, cols_total: int, level: int, torch, dist, device_index: int, slots: int = 1):
         from .matrix import GpuDCRTPolyMatrix
 
         self.torch, self.dist, self.device_index = torch, dist, device_index
@@ -127,37 +139,53 @@ class ColumnAllGather:
         self.ranges = all_shard_ranges(cols_total, self.world)
         self.padded = padded_len(cols_total, self.world)
         self.direct = rows == 1 and all(len(r) == self.padded for r in self.ranges)
-        self.full = GpuDCRTPolyMatrix(params, rows, cols_total, level, True)
-        self._full_t = DeviceBuffer(self.full).tensor(device_index)
-        if not self.direct:
-            self._send = GpuDCRTPolyMatrix(params, rows, self.padded, level, True)
-            self._recv = GpuDCRTPolyMatrix(params, self.world * rows, self.padded, level, True)
-            self._send_t = DeviceBuffer(self._send).tensor(device_index)
-            self._recv_t = DeviceBuffer(self._recv).tensor(device_index)
+        self._stream = engine_stream(params, torch, device_index)
+        self._slots = []
+        for _ in range(max(1, slots)):
+            slot = {"full": GpuDCRTPolyMatrix(params, rows, cols_total, level, True)}
+            slot["full_t"] = DeviceBuffer(slot["full"]).tensor(device_index)
+            if not self.direct:
+                slot["send"] = GpuDCRTPolyMatrix(params, rows, self.padded, level, True)
+                slot["recv"] = GpuDCRTPolyMatrix(params, self.world * rows, self.padded, level, True)
+                slot["send_t"] = DeviceBuffer(slot["send"]).tensor(device_index)
+                slot["recv_t"] = DeviceBuffer(slot["recv"]).tensor(device_index)
+            self._slots.append(slot)
 
-    def gather(self, local):
-        """local: this rank's rows x len(shard) block (EVAL or COEFF).  Returns the full matrix, valid
-        on the engine's stream when this returns."""
-        from ._ffi import gpu_device_sync
+    @property
+    def full(self):
+        return self._slots[0]["full"]
 
+    def start(self, local, slot: int = 0):
+        """Enqueue the gather of `local` (this rank's rows x len(shard) block, EVAL or COEFF) into buffer `slot`.
+        Returns a handle for `finish`; `local` and the slot's buffers must not be written until then."""
+        s = self._slots[slot]
         mine = self.ranges[self.rank]
         assert local.nrow == self.rows and local.ncol == len(mine), "local block does not match this rank's shard"
         if self.direct:
-            assert local.is_ntt == self.full.is_ntt, "direct gather keeps the full matrix's format tag"
-            gpu_device_sync()  # engine -> collective
-            self.dist.all_gather_into_tensor(self._full_t, DeviceBuffer(local).tensor(self.device_index))
-            self.torch.cuda.current_stream().synchronize()  # collective -> engine
+            send_t, recv_t = DeviceBuffer(local).tensor(self.device_index), s["full_t"]
         else:
-            send_t = self._send_t
+            send_t, recv_t = s["send_t"], s["recv_t"]
             if len(mine) == self.padded:
                 send_t = DeviceBuffer(local).tensor(self.device_index)  # a full-width shard is its own send buffer
             elif len(mine):
-                self._send.copy_block_from(local, 0, 0, 0, 0, self.rows, len(mine))
-            gpu_device_sync()
-            self.dist.all_gather_into_tensor(self._recv_t, send_t)
-            self.torch.cuda.current_stream().synchronize()
+                s["send"].copy_block_from(local, 0, 0, 0, 0, self.rows, len(mine))
+        with self.torch.cuda.stream(self._stream):  # the collective waits for the engine's queued work
+            work = self.dist.all_gather_into_tensor(recv_t, send_t, async_op=True)
+        return (work, slot, local, send_t)
+
+    def finish(self, pending):
+        """The engine's stream waits (on the device) for the gather; returns the full matrix of its slot."""
+        work, slot, local, _send_t = pending
+        s = self._slots[slot]
+        with self.torch.cuda.stream(self._stream):
+            work.wait()
+        if not self.direct:
             for r, sr in enumerate(self.ranges):
                 if len(sr):
-                    self.full.copy_block_from(self._recv, 0, sr.start, r * self.rows, 0, self.rows, len(sr))
-        self.full.is_ntt = local.is_ntt
-        return self.full
+                    s["full"].copy_block_from(s["recv"], 0, sr.start, r * self.rows, 0, self.rows, len(sr))
+        s["full"].is_ntt = local.is_ntt
+        return s["full"]
+
+    def gather(self, local, slot: int = 0):
+        """local: this rank's rows x len(shard) block.  Returns the full matrix, valid on the engine's stream."""
+        return self.finish(self.start(local, slot))

@@ -141,6 +141,12 @@ class GpuContext:
         _ffi.check_status(_ffi.lib().gpupoly_context_device(self.raw, C.byref(d)), "gpupoly_context_device")
         return d.value
 
+    def stream_handle(self) -> int:
+        """The context's compute stream as an integer hipStream_t (for `torch.cuda.ExternalStream`)."""
+        h = C.c_void_p()
+        _ffi.check_status(_ffi.lib().gpupoly_context_stream(self.raw, C.byref(h)), "gpupoly_context_stream")
+        return h.value or 0
+
     def word_bytes(self) -> int:
         d = C.c_int(0)
         _ffi.check_status(_ffi.lib().gpupoly_context_word_bytes(self.raw, C.byref(d)), "gpupoly_context_word_bytes")
