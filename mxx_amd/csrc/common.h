@@ -39,7 +39,7 @@ struct EnvSwitches {
     int ntt_path = 0;             // MXX_HIP_NTT_PATH: 0 auto, 1 lds, 2 generic, 3 global
     int ntt14 = 0;                // MXX_HIP_NTT14: 0 grouped signed, 1 whole-vector kernel, 2 grouped unsigned
     bool decompose_fused = true;  // MXX_HIP_DECOMPOSE_FUSED=0 disables digits-in-the-NTT-load
-    char matmul_path = 0;         // MXX_HIP_MATMUL_PATH: 0 auto, 'r' reg, 'l' lds, 'd' dma, 'm' mfma
+    char matmul_path = 0;         // MXX_HIP_MATMUL_PATH: 0 auto, 'r' reg, 'l' lds, 'd' dma, 'w' dma32 (wide tile), 'm' mfma
     bool gsamp_simple = false;    // MXX_HIP_GSAMP=simple
     bool p1_simple = false;       // MXX_HIP_P1=simple
     int sampler_per_lane = 0;     // MXX_HIP_SAMPLER_PER_LANE (0 = sized for one resident round)
@@ -188,6 +188,7 @@ int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t
 int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, const uint32_t *w, size_t vectors, uint32_t L);
 int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
 int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // -1: shape not supported
+int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // 32 slots x 32x32 tile
 int launch_matmul_mfma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // -1: shape / moduli not supported
 int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,
                       size_t src_col, size_t rows, size_t cols, bool add);

@@ -216,6 +216,219 @@ __global__ void __launch_bounds__(512, 2)
 }
 }  // namespace mmdma
 
+// ---- the same kernel with HALF the slots and TWICE the tile -------------------------------------------------------
+// Operand delivery is what bounds kernel_u32: a workgroup moves (TROWS + TCOLS) x KC rows per TROWS x TCOLS x KC MACs
+// per slot, i.e. 4 (32 + 16) / (32 x 16) = 0.375 bytes per MAC = 12.9 GB for M2b through an L2 -> LDS path that
+// delivers ~5 TB/s.  Bytes per MAC depend on the tile's shape only, and the tile is bounded by the accumulators (64
+// outputs x 64 bits per lane): the way to a larger tile is FEWER SLOTS per workgroup.  Here a workgroup owns 32
+// consecutive slots x a 32 x 32 tile: 0.25 bytes per MAC (8.6 GB), global rows of 128 bytes.  A wave is two halves of
+// 32 lanes: both halves work on the same 8 tile rows (their A reads coincide: LDS broadcast) and on column groups g
+// and g + 1, whose B rows are stored interleaved so that one ds_read covers 256 contiguous bytes.
+//   stage = A[32 rows][4 k][32 slots] + B[16 (column, k) pairs][2 groups][32 slots] = 32 KB, 3 stages = 96 KB
+namespace mmdma32 {
+using mmdma::ds_read2st64;
+using mmdma::lds_wait;
+using mmdma::static_for;
+constexpr int KC = 4, TROWS = 32, TCOLS = 32, STAGES = 4;
+constexpr uint32_t SLOTS = 32;
+constexpr uint32_t A_WORDS = TROWS * KC * SLOTS, B_WORDS = TCOLS * KC * SLOTS, STAGE_WORDS = A_WORDS + B_WORDS;
+constexpr size_t LDS_BYTES = static_cast<size_t>(STAGES) * STAGE_WORDS * sizeof(uint32_t);
+constexpr int LOADS_PER_WAVE = (TROWS + TCOLS) * KC / 8 / 8;  // an instruction moves 8 rows of 128 bytes: 4 per wave per stage
+
+__global__ void __launch_bounds__(512, 2)
+    kernel_u32(uint32_t *__restrict__ C, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
+               const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L, uint32_t N,
+               uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks, uint32_t xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tiles = row_tiles * col_tiles;
+    uint32_t id = blockIdx.x, tile, group;
+    if (xcd_remap) {
+        const uint32_t xcd = id & 7u, j = id >> 3;
+        tile = j % tiles;
+        group = (j / tiles) * 8u + xcd;
+    } else {
+        tile = id % tiles;
+        group = id / tiles;
+    }
+    const uint32_t limb = group / slot_chunks, chunk = group - limb * slot_chunks;
+    const uint32_t rt = tile / col_tiles, ct = tile - rt * col_tiles;
+    const uint32_t r0 = rt * TROWS, c0 = ct * TCOLS;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slot = lane & 31u, half = lane >> 5;
+    const uint32_t wr = wave >> 1, wp = wave & 1u;  // tile rows 8 wr .., column groups 2 wp + half
+    const LimbConst lc = limbs[limb];
+    const uint32_t q = static_cast<uint32_t>(lc.q);
+    const size_t polyw = static_cast<size_t>(L) * N;
+    const size_t slot_base = static_cast<size_t>(limb) * N + chunk * SLOTS;
+
+    // loader: instruction j of this wave fills LDS rows rho = (4 wave + j) 8 + lane / 8 (128 bytes each); a lane
+    // supplies slots 4 (lane % 8) .. + 3 of its row.  Rows 0..127: A, row = i * 4 + k.  Rows 128..255: B,
+    // row - 128 = (((g >> 1) * 8 + c) * 4 + k) * 2 + (g & 1) for column 8 g + c of the tile.
+    const uint32_t *src[LOADS_PER_WAVE];
+    const size_t stride_a = static_cast<size_t>(KC) * polyw, stride_b = static_cast<size_t>(KC) * cols * polyw;
+#pragma unroll
+    for (int j = 0; j < LOADS_PER_WAVE; ++j) {
+        const uint32_t rho = (wave * LOADS_PER_WAVE + j) * 8u + (lane >> 3);
+        const uint32_t part = (lane & 7u) * 4u;
+        if (rho < TROWS * KC) {
+            const uint32_t i = rho >> 2, k = rho & 3u;
+            const uint32_t rr = min(r0 + i, rows - 1);
+            src[j] = A + (static_cast<size_t>(rr) * inner + k) * polyw + slot_base + part;
+        } else {
+            const uint32_t rb = rho - TROWS * KC, g0 = rb & 1u, t = rb >> 1, k = t & 3u, u = t >> 2;
+            const uint32_t c = (((u >> 3) * 2u + g0) << 3) + (u & 7u);
+            const uint32_t cc = min(c0 + c, cols - 1);
+            src[j] = B + (static_cast<size_t>(k) * cols + cc) * polyw + slot_base + part;
+        }
+    }
+    auto issue = [&](uint32_t stage) {
+#pragma unroll
+        for (int j = 0; j < LOADS_PER_WAVE; ++j) {
+            const uint32_t row0 = (wave * LOADS_PER_WAVE + j) * 8u;  // wave-uniform
+            __builtin_amdgcn_global_load_lds(src[j], lds + stage * STAGE_WORDS + row0 * SLOTS, 16, 0, 0);
+            src[j] += row0 < TROWS * KC ? stride_a : stride_b;
+        }
+    };
+
+    uint64_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+
+    const uint32_t nch = inner / KC;
+    const uint32_t lazy = lc.lazy_terms;
+    uint32_t pending = 0;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+    // A word (i, k, slot) sits at i * 128 + k * 32 + slot: k = 0, 2 are 0 / 64 words past `a_even`, k = 1, 3 past `a_odd`
+    const uint32_t a_even = lds0 + (wr * 8u * KC * SLOTS + slot) * 4u, a_odd = a_even + SLOTS * 4u;
+    // B word (group 2 wp + half, c, k, slot) sits at ((wp * 8 + c) * 4 + k) * 64 + half * 32 + slot
+    const uint32_t b_addr = lds0 + (A_WORDS + wp * 8u * KC * 2u * SLOTS + half * SLOTS + slot) * 4u;
+    constexpr uint32_t STAGE_BYTES = STAGE_WORDS * 4u;
+
+    // a[i][0] = (k0, k2), a[i][1] = (k1, k3) of tile row 8 wr + i
+    auto step = [&](uint32_t ch, uint32_t stage, uint64_t (&a_cur)[8][2], uint64_t (&a_nxt)[8][2]) {
+        const uint32_t next_stage = (stage + 1) % STAGES;
+        const bool more = ch + 1 < nch;
+        // chunk ch+1 must have landed; chunk ch+2 (issued one step ago) may stay in flight
+        if (more) {
+            if (ch + 2 < nch) MMDMA_WAIT_VM(LOADS_PER_WAVE);
+            else MMDMA_WAIT_VM(0);
+        }
+        asm volatile("s_barrier" ::: "memory");   // ... for every wave, and everyone is done with chunk ch-1
+        if (ch + 3 < nch) issue((stage + 3) % STAGES);  // into the stage chunk ch-1 has just left
+        const uint32_t sb = b_addr + stage * STAGE_BYTES;
+        const uint32_t off = (more ? next_stage : stage) * STAGE_BYTES;  // last chunk: harmless re-read
+        const uint32_t sae = a_even + off, sao = a_odd + off;
+        // B values are read TWO columns ahead (three register pairs in rotation): at two waves per SIMD one column's
+        // 32 multiply-adds (~160 cycles) do not cover an LDS round trip while eight waves share the port
+        uint64_t b[3][2];
+        b[0][0] = ds_read2st64<0, 1>(sb);
+        b[0][1] = ds_read2st64<2, 3>(sb);
+        b[1][0] = ds_read2st64<4, 5>(sb);
+        b[1][1] = ds_read2st64<6, 7>(sb);
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int cur = j % 3, ahead = (j + 2) % 3;
+            if constexpr (j + 2 < 8) {
+                b[ahead][0] = ds_read2st64<4 * (j + 2), 4 * (j + 2) + 1>(sb);
+                b[ahead][1] = ds_read2st64<4 * (j + 2) + 2, 4 * (j + 2) + 3>(sb);
+            }
+            a_nxt[j][0] = ds_read2st64<2 * j, 2 * j + 1>(sae);
+            a_nxt[j][1] = ds_read2st64<2 * j, 2 * j + 1>(sao);
+            // LDS reads issued after b[cur]'s pair (they complete in order): the B pairs of the columns up to j+2 and
+            // the A rows of the steps since
+            constexpr int younger_b = (j == 0 ? 2 : (j + 2 < 8 ? 2 : (j + 1 < 8 ? 1 : 0)));
+            constexpr int younger_a = (j == 0 ? 1 : (j == 1 ? 2 : 3));
+            lds_wait<2 * (younger_a + younger_b)>(b[cur][0], b[cur][1]);
+            const uint32_t bk[KC] = {static_cast<uint32_t>(b[cur][0]), static_cast<uint32_t>(b[cur][0] >> 32),
+                                     static_cast<uint32_t>(b[cur][1]), static_cast<uint32_t>(b[cur][1] >> 32)};
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t av = (k & 2) ? static_cast<uint32_t>(a_cur[i][k & 1] >> 32) : static_cast<uint32_t>(a_cur[i][k & 1]);
+                    acc[i][j] += static_cast<uint64_t>(av) * bk[k];
+                }
+        });
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_wait<0>(a_nxt[i][0], a_nxt[i][1]);
+        pending += KC;
+        if (pending + KC > lazy) {
+            pending = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+        }
+    };
+
+    uint64_t a0[8][2], a1[8][2];
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 2) issue(2);
+    if (nch > 2) MMDMA_WAIT_VM(2 * LOADS_PER_WAVE);
+    else if (nch > 1) MMDMA_WAIT_VM(LOADS_PER_WAVE);
+    else MMDMA_WAIT_VM(0);
+    asm volatile("s_barrier" ::: "memory");
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        a0[i][0] = ds_read2st64<2 * i, 2 * i + 1>(a_even);
+        a0[i][1] = ds_read2st64<2 * i, 2 * i + 1>(a_odd);
+    });
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lds_wait<0>(a0[i][0], a0[i][1]);
+    uint32_t stage = 0;
+    for (uint32_t ch = 0; ch < nch; ch += 2) {
+        step(ch, stage, a0, a1);
+        stage = (stage + 1) % STAGES;
+        if (ch + 1 < nch) {
+            step(ch + 1, stage, a1, a0);
+            stage = (stage + 1) % STAGES;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = r0 + wr * 8 + i;
+        if (r >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t c = c0 + (wp * 2u + half) * 8u + j;
+            if (c >= cols) continue;
+            C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+        }
+    }
+}
+}  // namespace mmdma32
+
+// 32 slots x 32 x 32 tile per workgroup; -1: shape not supported
+int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
+    GpuContext *ctx = out->ctx;
+    const uint32_t rows = static_cast<uint32_t>(lhs->rows), inner = static_cast<uint32_t>(lhs->cols),
+                   cols = static_cast<uint32_t>(rhs->cols);
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(out)), N = static_cast<uint32_t>(ctx->N);
+    if (ctx->wide || N < mmdma32::SLOTS || (N % mmdma32::SLOTS) != 0 || inner < mmdma32::KC || (inner % mmdma32::KC) != 0) return -1;
+    const uint32_t row_tiles = (rows + mmdma32::TROWS - 1) / mmdma32::TROWS, col_tiles = (cols + mmdma32::TCOLS - 1) / mmdma32::TCOLS;
+    const uint32_t slot_chunks = N / mmdma32::SLOTS;
+    const uint64_t groups = static_cast<uint64_t>(L) * slot_chunks;
+    const uint64_t blocks = groups * row_tiles * col_tiles;
+    if (blocks > 0x7fffffffull) return set_error("gpu_matrix_mul: matrix too large");
+    static std::atomic<uint64_t> configured{0};
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (!(configured.load() & bit)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mmdma32::kernel_u32),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mmdma32::LDS_BYTES)));
+        configured.fetch_or(bit);
+    }
+    const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
+    hipLaunchKernelGGL(mmdma32::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(512), mmdma32::LDS_BYTES, ctx->stream,
+                       static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
+                       static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
+                       col_tiles, slot_chunks, remap);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // -1: shape not supported (the caller falls back to the register-staged LDS kernel)
 int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
     GpuContext *ctx = out->ctx;

@@ -203,11 +203,13 @@ def test_matmul_kernel_families(gpu, oracle, hip_env, path, shape):
     assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
 
 
-@pytest.mark.parametrize("shape", [(32, 8, 16), (33, 12, 17), (64, 64, 64), (16, 4, 8), (40, 36, 5), (3, 16, 70)])
+@pytest.mark.parametrize("shape", [(32, 8, 16), (33, 12, 17), (64, 64, 64), (16, 4, 8), (40, 36, 5), (3, 16, 70), (32, 4, 32), (65, 20, 33)])
 @pytest.mark.parametrize("bits", [24, 31])
-def test_matmul_dma_kernel(gpu, oracle, hip_env, shape, bits):
-    """global->LDS streamed product (matmul_dma.hip): full and ragged 32x16 tiles, inner % 4 == 0, and
-    31-bit primes whose accumulators must be folded every chunk; worst-case residues q-1 in one operand."""
+@pytest.mark.parametrize("path", ["dma", "wide"])
+def test_matmul_dma_kernel(gpu, oracle, hip_env, shape, bits, path):
+    """global->LDS streamed products (matmul_dma.hip; "dma": 64 slots x 32x16 tile, "wide": 32 slots x 32x32 tile):
+    full and ragged tiles, inner % 4 == 0, and 31-bit primes whose accumulators must be folded every chunk;
+    worst-case residues q-1 in one operand."""
     r, k, c = shape
     n = 128
     moduli = oracle.gen_crt_basis(n, 2, bits)
@@ -217,7 +219,7 @@ def test_matmul_dma_kernel(gpu, oracle, hip_env, shape, bits):
     b[::2] = rand_matrix(oracle, 28, k, c, moduli, n)[::2]
     ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
     gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
-    hip_env.set("MXX_HIP_MATMUL_PATH", "dma")
+    hip_env.set("MXX_HIP_MATMUL_PATH", path)
     assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
 
 

@@ -250,6 +250,8 @@ def test_matmul_mfma_equals_valu_at_full_size(gpu, oracle, hip_env):
     want = a * b
     hip_env.set("MXX_HIP_MATMUL_PATH", "mfma")
     assert a * b == want
+    hip_env.set("MXX_HIP_MATMUL_PATH", "wide")
+    assert a * b == want
 
 
 @pytest.mark.parametrize("shape,n", [((2, 72, 4), 256), ((5, 9, 7), 256), ((1, 3, 1), 64), ((8, 40, 9), 4096), ((3, 70, 5), 16)])
