@@ -434,8 +434,8 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
             const int rc = launch_matmul_mfma_u32(out, lhs, rhs);
             if (rc >= 0) return rc;
         }
-        // 32 slots x 32x32 tile (a quarter less operand traffic per MAC, four-stage ring): wins when it wastes no
-        // more tile area than the 64-slot 32x16 kernel (64^3: 2.40 against 2.56 ms)
+        // 32 slots x 32x32 tile, 16 waves (a third less operand traffic per MAC, four-stage ring): wins when it
+        // wastes no more tile area than the 64-slot 32x16 kernel (64^3: 2.15 against 2.43 ms)
         const bool want_wide = force ? (force == 'w') : (rows >= 32 && cols >= 32 && ((cols + 31) / 32) * 2 <= (cols + 15) / 16);
         if (want_wide) {
             const int rc = launch_matmul_dma32_u32(out, lhs, rhs);

@@ -188,7 +188,7 @@ int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t
 int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, const uint32_t *w, size_t vectors, uint32_t L);
 int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
 int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // -1: shape not supported
-int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // 32 slots x 32x32 tile
+int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // 32 slots x 32x32 tile, 16 waves
 int launch_matmul_mfma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // -1: shape / moduli not supported
 int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size_t dst_col, size_t src_row,
                       size_t src_col, size_t rows, size_t cols, bool add);

@@ -48,6 +48,13 @@ __device__ __forceinline__ uint64_t ds_read2st64(uint32_t addr) {
     asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF0), "n"(OFF1));
     return v;
 }
+// one dword OFF bytes past `addr`
+template <int OFF>
+__device__ __forceinline__ uint32_t ds_read_at(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
 // wait until at most N LDS reads issued after them are outstanding; ties the four words to the wait
 template <int N>
 __device__ __forceinline__ void lds_wait(uint64_t &x, uint64_t &y) {
@@ -202,29 +209,37 @@ __global__ void __launch_bounds__(512, 2)
             stage = stage + 1 == STAGES ? 0 : stage + 1;
         }
     }
+    const BoundedReduce br = bounded_reduce_setup(lc.kbits, lc.mu64, inner);
+    auto store_tile = [&](auto reduce) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t r = r0 + wr * 8 + i;
-        if (r >= rows) continue;
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t r = r0 + wr * 8 + i;
+            if (r >= rows) continue;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t c = c0 + wc * 8 + j;
-            if (c >= cols) continue;
-            C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t c = c0 + wc * 8 + j;
+                if (c >= cols) continue;
+                C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane] = reduce(acc[i][j]);
+            }
         }
-    }
+    };
+    if (br.ok) store_tile([&](uint64_t v) { return reduce_u64_bounded(v, q, br); });
+    else store_tile([&](uint64_t v) { return reduce_u64_sum(v, q, lc.mu64); });
 }
 }  // namespace mmdma
 
-// ---- the same kernel with HALF the slots and TWICE the tile -------------------------------------------------------
-// Operand delivery is what bounds kernel_u32: a workgroup moves (TROWS + TCOLS) x KC rows per TROWS x TCOLS x KC MACs
-// per slot, i.e. 4 (32 + 16) / (32 x 16) = 0.375 bytes per MAC = 12.9 GB for M2b through an L2 -> LDS path that
-// delivers ~5 TB/s.  Bytes per MAC depend on the tile's shape only, and the tile is bounded by the accumulators (64
-// outputs x 64 bits per lane): the way to a larger tile is FEWER SLOTS per workgroup.  Here a workgroup owns 32
-// consecutive slots x a 32 x 32 tile: 0.25 bytes per MAC (8.6 GB), global rows of 128 bytes.  A wave is two halves of
-// 32 lanes: both halves work on the same 8 tile rows (their A reads coincide: LDS broadcast) and on column groups g
-// and g + 1, whose B rows are stored interleaved so that one ds_read covers 256 contiguous bytes.
-//   stage = A[32 rows][4 k][32 slots] + B[16 (column, k) pairs][2 groups][32 slots] = 32 KB, 3 stages = 96 KB
+// ---- the same product with HALF the slots, TWICE the tile and 16 waves ----------------------------------------------
+// Operand delivery bounds kernel_u32 above: a workgroup moves (TROWS + TCOLS) x KC rows per TROWS x TCOLS x KC MACs per
+// slot, i.e. 4 (32 + 16) / (32 x 16) = 0.375 bytes per MAC = 12.9 GB for M2b through an L2 -> LDS path that delivers
+// ~5 TB/s (2.43 ms).  Bytes per MAC depend on the tile's shape only, and the tile is bounded by the accumulators: the
+// way to a larger tile is FEWER SLOTS per workgroup.  Here a workgroup owns 32 consecutive slots x a 32 x 32 tile:
+// 0.25 bytes per MAC (8.6 GB), global rows of 128 bytes, and the freed LDS holds a four-stage ring (loads issued three
+// chunks ahead).  A wave is two halves of 32 lanes on the same 8 tile rows (their A reads coincide: LDS broadcast)
+// and on adjacent groups of 4 columns, whose B rows are stored interleaved so that one ds_read covers 256 contiguous
+// bytes.  A lane owns 8 rows x 4 columns (64 accumulator registers): 1024 threads, four waves per SIMD - with 8 x 8
+// per lane (128 registers, two waves per SIMD, LDS reads software-pipelined by hand) the same tile ran 2.25 ms, this
+// form 2.15 ms; no software pipelining of the LDS reads here (no registers left for it), the other waves cover them.
+//   stage = A[32 rows][4 k][32 slots] + B[32 columns][4 k][32 slots] = 32 KB, 4 stages = 128 KB
 namespace mmdma32 {
 using mmdma::ds_read2st64;
 using mmdma::lds_wait;
@@ -233,9 +248,9 @@ constexpr int KC = 4, TROWS = 32, TCOLS = 32, STAGES = 4;
 constexpr uint32_t SLOTS = 32;
 constexpr uint32_t A_WORDS = TROWS * KC * SLOTS, B_WORDS = TCOLS * KC * SLOTS, STAGE_WORDS = A_WORDS + B_WORDS;
 constexpr size_t LDS_BYTES = static_cast<size_t>(STAGES) * STAGE_WORDS * sizeof(uint32_t);
-constexpr int LOADS_PER_WAVE = (TROWS + TCOLS) * KC / 8 / 8;  // an instruction moves 8 rows of 128 bytes: 4 per wave per stage
+constexpr int LOADS_PER_WAVE = (TROWS + TCOLS) * KC / 8 / 16;  // 2 instructions (8 rows of 128 bytes each) per wave per stage
 
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(1024, 4)
     kernel_u32(uint32_t *__restrict__ C, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
                const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L, uint32_t N,
                uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks, uint32_t xcd_remap) {
@@ -255,15 +270,14 @@ __global__ void __launch_bounds__(512, 2)
     const uint32_t r0 = rt * TROWS, c0 = ct * TCOLS;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = lane & 31u, half = lane >> 5;
-    const uint32_t wr = wave >> 1, wp = wave & 1u;  // tile rows 8 wr .., column groups 2 wp + half
+    const uint32_t wr = wave >> 2, wq = wave & 3u;  // tile rows 8 wr .., columns 8 wq + 4 half ..
     const LimbConst lc = limbs[limb];
     const uint32_t q = static_cast<uint32_t>(lc.q);
     const size_t polyw = static_cast<size_t>(L) * N;
     const size_t slot_base = static_cast<size_t>(limb) * N + chunk * SLOTS;
 
-    // loader: instruction j of this wave fills LDS rows rho = (4 wave + j) 8 + lane / 8 (128 bytes each); a lane
-    // supplies slots 4 (lane % 8) .. + 3 of its row.  Rows 0..127: A, row = i * 4 + k.  Rows 128..255: B,
-    // row - 128 = (((g >> 1) * 8 + c) * 4 + k) * 2 + (g & 1) for column 8 g + c of the tile.
+    // LDS rows of 128 bytes.  0..127: A, row = i * 4 + k.  128..255: B, row - 128 = ((cq * 4 + cj) * 4 + k) * 2 + ch for
+    // tile column 8 cq + 4 ch + cj: the two half-waves of a wave read adjacent rows.
     const uint32_t *src[LOADS_PER_WAVE];
     const size_t stride_a = static_cast<size_t>(KC) * polyw, stride_b = static_cast<size_t>(KC) * cols * polyw;
 #pragma unroll
@@ -275,8 +289,8 @@ __global__ void __launch_bounds__(512, 2)
             const uint32_t rr = min(r0 + i, rows - 1);
             src[j] = A + (static_cast<size_t>(rr) * inner + k) * polyw + slot_base + part;
         } else {
-            const uint32_t rb = rho - TROWS * KC, g0 = rb & 1u, t = rb >> 1, k = t & 3u, u = t >> 2;
-            const uint32_t c = (((u >> 3) * 2u + g0) << 3) + (u & 7u);
+            const uint32_t rb = rho - TROWS * KC, ch = rb & 1u, t = rb >> 1, k = t & 3u, u = t >> 2;
+            const uint32_t c = ((u >> 2) << 3) + (ch << 2) + (u & 3u);
             const uint32_t cc = min(c0 + c, cols - 1);
             src[j] = B + (static_cast<size_t>(k) * cols + cc) * polyw + slot_base + part;
         }
@@ -290,114 +304,88 @@ __global__ void __launch_bounds__(512, 2)
         }
     };
 
-    uint64_t acc[8][8];
+    uint64_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
 
     const uint32_t nch = inner / KC;
     const uint32_t lazy = lc.lazy_terms;
     uint32_t pending = 0;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
-    // A word (i, k, slot) sits at i * 128 + k * 32 + slot: k = 0, 2 are 0 / 64 words past `a_even`, k = 1, 3 past `a_odd`
-    const uint32_t a_even = lds0 + (wr * 8u * KC * SLOTS + slot) * 4u, a_odd = a_even + SLOTS * 4u;
-    // B word (group 2 wp + half, c, k, slot) sits at ((wp * 8 + c) * 4 + k) * 64 + half * 32 + slot
-    const uint32_t b_addr = lds0 + (A_WORDS + wp * 8u * KC * 2u * SLOTS + half * SLOTS + slot) * 4u;
+    const uint32_t b_addr = lds0 + (A_WORDS + wq * 4u * KC * 2u * SLOTS + half * SLOTS + slot) * 4u;
     constexpr uint32_t STAGE_BYTES = STAGE_WORDS * 4u;
 
-    // a[i][0] = (k0, k2), a[i][1] = (k1, k3) of tile row 8 wr + i
-    auto step = [&](uint32_t ch, uint32_t stage, uint64_t (&a_cur)[8][2], uint64_t (&a_nxt)[8][2]) {
-        const uint32_t next_stage = (stage + 1) % STAGES;
-        const bool more = ch + 1 < nch;
-        // chunk ch+1 must have landed; chunk ch+2 (issued one step ago) may stay in flight
-        if (more) {
-            if (ch + 2 < nch) MMDMA_WAIT_VM(LOADS_PER_WAVE);
-            else MMDMA_WAIT_VM(0);
-        }
-        asm volatile("s_barrier" ::: "memory");   // ... for every wave, and everyone is done with chunk ch-1
-        if (ch + 3 < nch) issue((stage + 3) % STAGES);  // into the stage chunk ch-1 has just left
-        const uint32_t sb = b_addr + stage * STAGE_BYTES;
-        const uint32_t off = (more ? next_stage : stage) * STAGE_BYTES;  // last chunk: harmless re-read
-        const uint32_t sae = a_even + off, sao = a_odd + off;
-        // B values are read TWO columns ahead (three register pairs in rotation): at two waves per SIMD one column's
-        // 32 multiply-adds (~160 cycles) do not cover an LDS round trip while eight waves share the port
-        uint64_t b[3][2];
-        b[0][0] = ds_read2st64<0, 1>(sb);
-        b[0][1] = ds_read2st64<2, 3>(sb);
-        b[1][0] = ds_read2st64<4, 5>(sb);
-        b[1][1] = ds_read2st64<6, 7>(sb);
-        static_for<8>([&](auto jc) {
+    // All of a chunk's LDS reads sit at its top (no registers are left to keep a second operand set in flight: 64
+    // accumulators + 48 operand words; splitting the chunk into k-steps with two small sets made the compiler spill
+    // and copy registers whose reads were still in flight).  The other three waves of the SIMD cover the wait.
+    const uint32_t a_even = lds0 + (wr * 8u * KC * SLOTS + slot) * 4u, a_odd = a_even + SLOTS * 4u;
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 2) issue(2);
+    uint32_t stage = 0;
+    for (uint32_t ch = 0; ch < nch; ++ch) {
+        // chunk ch must have landed; up to two younger chunks stay in flight
+        if (ch + 2 < nch) MMDMA_WAIT_VM(2 * LOADS_PER_WAVE);
+        else if (ch + 1 < nch) MMDMA_WAIT_VM(LOADS_PER_WAVE);
+        else MMDMA_WAIT_VM(0);
+        asm volatile("s_barrier" ::: "memory");  // ... for every wave, and everyone is done with chunk ch-1
+        if (ch + 3 < nch) issue((stage + 3) % STAGES);
+        const uint32_t off = stage * STAGE_BYTES;
+        uint64_t a[8][2], b[4][2];
+        static_for<4>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            constexpr int cur = j % 3, ahead = (j + 2) % 3;
-            if constexpr (j + 2 < 8) {
-                b[ahead][0] = ds_read2st64<4 * (j + 2), 4 * (j + 2) + 1>(sb);
-                b[ahead][1] = ds_read2st64<4 * (j + 2) + 2, 4 * (j + 2) + 3>(sb);
-            }
-            a_nxt[j][0] = ds_read2st64<2 * j, 2 * j + 1>(sae);
-            a_nxt[j][1] = ds_read2st64<2 * j, 2 * j + 1>(sao);
-            // LDS reads issued after b[cur]'s pair (they complete in order): the B pairs of the columns up to j+2 and
-            // the A rows of the steps since
-            constexpr int younger_b = (j == 0 ? 2 : (j + 2 < 8 ? 2 : (j + 1 < 8 ? 1 : 0)));
-            constexpr int younger_a = (j == 0 ? 1 : (j == 1 ? 2 : 3));
-            lds_wait<2 * (younger_a + younger_b)>(b[cur][0], b[cur][1]);
-            const uint32_t bk[KC] = {static_cast<uint32_t>(b[cur][0]), static_cast<uint32_t>(b[cur][0] >> 32),
-                                     static_cast<uint32_t>(b[cur][1]), static_cast<uint32_t>(b[cur][1] >> 32)};
+            b[j][0] = ds_read2st64<4 * j, 4 * j + 1>(b_addr + off);      // (k0, k1)
+            b[j][1] = ds_read2st64<4 * j + 2, 4 * j + 3>(b_addr + off);  // (k2, k3)
+        });
+        static_for<8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            a[i][0] = ds_read2st64<2 * i, 2 * i + 1>(a_even + off);  // (k0, k2)
+            a[i][1] = ds_read2st64<2 * i, 2 * i + 1>(a_odd + off);   // (k1, k3)
+        });
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_wait<0>(b[j][0], b[j][1]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_wait<0>(a[i][0], a[i][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t bk[KC] = {static_cast<uint32_t>(b[j][0]), static_cast<uint32_t>(b[j][0] >> 32),
+                                     static_cast<uint32_t>(b[j][1]), static_cast<uint32_t>(b[j][1] >> 32)};
 #pragma unroll
             for (int k = 0; k < KC; ++k)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const uint32_t av = (k & 2) ? static_cast<uint32_t>(a_cur[i][k & 1] >> 32) : static_cast<uint32_t>(a_cur[i][k & 1]);
+                    const uint32_t av = (k & 2) ? static_cast<uint32_t>(a[i][k & 1] >> 32) : static_cast<uint32_t>(a[i][k & 1]);
                     acc[i][j] += static_cast<uint64_t>(av) * bk[k];
                 }
-        });
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lds_wait<0>(a_nxt[i][0], a_nxt[i][1]);
+        }
         pending += KC;
         if (pending + KC > lazy) {
             pending = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+                for (int j = 0; j < 4; ++j) acc[i][j] = reduce_u64_sum(acc[i][j], q, lc.mu64);
+        }
+        stage = (stage + 1) % STAGES;
+    }
+    const BoundedReduce br = bounded_reduce_setup(lc.kbits, lc.mu64, inner);
+    auto store_tile = [&](auto reduce) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t r = r0 + wr * 8 + i;
+            if (r >= rows) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = c0 + wq * 8u + half * 4u + j;
+                if (c >= cols) continue;
+                C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot] = reduce(acc[i][j]);
+            }
         }
     };
-
-    uint64_t a0[8][2], a1[8][2];
-    issue(0);
-    if (nch > 1) issue(1);
-    if (nch > 2) issue(2);
-    if (nch > 2) MMDMA_WAIT_VM(2 * LOADS_PER_WAVE);
-    else if (nch > 1) MMDMA_WAIT_VM(LOADS_PER_WAVE);
-    else MMDMA_WAIT_VM(0);
-    asm volatile("s_barrier" ::: "memory");
-    static_for<8>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        a0[i][0] = ds_read2st64<2 * i, 2 * i + 1>(a_even);
-        a0[i][1] = ds_read2st64<2 * i, 2 * i + 1>(a_odd);
-    });
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lds_wait<0>(a0[i][0], a0[i][1]);
-    uint32_t stage = 0;
-    for (uint32_t ch = 0; ch < nch; ch += 2) {
-        step(ch, stage, a0, a1);
-        stage = (stage + 1) % STAGES;
-        if (ch + 1 < nch) {
-            step(ch + 1, stage, a1, a0);
-            stage = (stage + 1) % STAGES;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t r = r0 + wr * 8 + i;
-        if (r >= rows) continue;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t c = c0 + (wp * 2u + half) * 8u + j;
-            if (c >= cols) continue;
-            C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot] = reduce_u64_sum(acc[i][j], q, lc.mu64);
-        }
-    }
+    if (br.ok) store_tile([&](uint64_t v) { return reduce_u64_bounded(v, q, br); });
+    else store_tile([&](uint64_t v) { return reduce_u64_sum(v, q, lc.mu64); });
 }
 }  // namespace mmdma32
 
@@ -421,7 +409,7 @@ int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatri
         configured.fetch_or(bit);
     }
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
-    hipLaunchKernelGGL(mmdma32::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(512), mmdma32::LDS_BYTES, ctx->stream,
+    hipLaunchKernelGGL(mmdma32::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(1024), mmdma32::LDS_BYTES, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
                        col_tiles, slot_chunks, remap);

@@ -84,6 +84,33 @@ __device__ __forceinline__ uint32_t reduce_u64_sum(uint64_t acc, uint32_t q, uin
     return static_cast<uint32_t>(r);
 }
 
+// The same reduction when a bound on the sum is known: acc < 2^W with W >= 32, q < 2^30 and W - bits(q) <= 31.
+// One 32-bit Barrett step on the top 32 of the W bits: t = acc >> (W - 32), qhat = hi32(t * floor(2^W / q)) is at most 3
+// short of the quotient, so the remainder fits 32 bits (< 4q) and two conditional subtractions finish: 8 VALU
+// instructions against ~17 for the 64 x 64 -> high-64 product above.  floor(2^W / q) = mu64 >> (64 - W).
+struct BoundedReduce {
+    uint32_t shift, mu;  // W - 32, floor(2^W / q)
+    bool ok;
+};
+__device__ __forceinline__ BoundedReduce bounded_reduce_setup(uint32_t kbits, uint64_t mu64, uint32_t terms) {
+    // sum of `terms` products of residues below 2^kbits
+    const uint32_t lg = terms <= 1 ? 0 : 32 - __builtin_clz(terms - 1);
+    uint32_t w = 2 * kbits + lg;
+    if (w < 32) w = 32;
+    BoundedReduce b;
+    b.ok = kbits <= 29 && w <= 63 && w - kbits <= 31;
+    b.shift = b.ok ? w - 32 : 0;
+    b.mu = b.ok ? static_cast<uint32_t>(mu64 >> (64 - w)) : 0;
+    return b;
+}
+__device__ __forceinline__ uint32_t reduce_u64_bounded(uint64_t acc, uint32_t q, const BoundedReduce &b) {
+    const uint32_t t = static_cast<uint32_t>(acc >> b.shift);
+    const uint32_t qhat = __umulhi(t, b.mu);
+    uint32_t r = static_cast<uint32_t>(acc) - qhat * q;  // true remainder estimate, in [0, 4q)
+    r = min(r, r - 2 * q);
+    return min(r, r - q);
+}
+
 // acc < 2^128 (lazily accumulated products of 64-bit residues), q < 2^62: result in [0,q).
 // acc = x1 2^64 + x0 = (x1 mod q) R + (x0 mod q) (mod q) with R = 2^64 mod q = -q mu64 (mod 2^64); the three
 // Barrett steps need their inputs below 2^(2k), which 64-bit words are once k >= 33.

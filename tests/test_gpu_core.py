@@ -207,7 +207,7 @@ def test_matmul_kernel_families(gpu, oracle, hip_env, path, shape):
 @pytest.mark.parametrize("bits", [24, 31])
 @pytest.mark.parametrize("path", ["dma", "wide"])
 def test_matmul_dma_kernel(gpu, oracle, hip_env, shape, bits, path):
-    """global->LDS streamed products (matmul_dma.hip; "dma": 64 slots x 32x16 tile, "wide": 32 slots x 32x32 tile):
+    """global->LDS streamed products (matmul_dma.hip; "dma": 64 slots x 32x16 tile, "wide": 32 slots x 32x32 tile, 16 waves):
     full and ragged tiles, inner % 4 == 0, and 31-bit primes whose accumulators must be folded every chunk;
     worst-case residues q-1 in one operand."""
     r, k, c = shape
