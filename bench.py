@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m3a", "m3b", "m4"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--gather", default="lazy", choices=["lazy", "step"],
+                    help="sharded mat-mul: all-gather the product's column blocks once per timed region (the consumer "
+                         "gathers when it needs the whole matrix) or after every step; the preimage gathers every call")
     ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K steps for median / min")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per block")
@@ -308,9 +311,14 @@ class MatMul(Workload):
             self.c_local = len(sr)
             self.b = uniform_matrix(mx, p, k, self.c_local, 5, total_cols=c, col_start=sr.start)
             self.gather = ColumnAllGather(p, r, c, L - 1, d.torch, d.dist, self.device, slots=2)
-            self.sharding = (f"strong: B/C column blocks by shard_range ({c} -> {self.c_local} on this rank), "
-                             "A replicated, one RCCL all-gather of C's blocks per step, ordered on the device and "
-                             "overlapped with the next step's product (two buffer slots)")
+            self.lazy_gather = self.args.gather == "lazy"
+            how = ("the blocks stay sharded between steps and are all-gathered (RCCL, on the device's stream order) ONCE "
+                   "per timed region, inside it - the full C is larger than what a rank reads for its product and xGMI is "
+                   "~20x slower than HBM, so a consumer gathers when it needs the whole matrix (SURVEY 8e)"
+                   if self.lazy_gather else
+                   "one RCCL all-gather of C's blocks per step, ordered on the device and overlapped with the next "
+                   "step's product (two buffer slots)")
+            self.sharding = (f"strong: B/C column blocks by shard_range ({c} -> {self.c_local} on this rank), A replicated; " + how)
             self.units_total = r * k * c  # the whole job's ring-ops per step
         else:
             self.c_local = c
@@ -318,6 +326,7 @@ class MatMul(Workload):
             self.gather = None
             self.sharding = "weak: every rank multiplies the full shape, no collective" if d.world > 1 else "single GPU"
             self.units_total = r * k * c * d.world
+        self.lazy_gather, self._ungathered = getattr(self, "lazy_gather", False), False
         self.outs = [mx.GpuDCRTPolyMatrix(p, r, max(self.c_local, 1), L - 1, True) for _ in range(2 if self.gather else 1)]
         self.out = self.outs[0]
         self.units = self.units_total
@@ -330,15 +339,26 @@ class MatMul(Workload):
     def step(self, i, mark):
         from mxx_amd import _ffi
 
-        slot = self.gather_begin(i)
-        self.out = self.outs[slot if self.gather else 0]
+        per_step = self.gather is not None and not self.lazy_gather
+        slot = self.gather_begin(i) if per_step else 0
+        self.out = self.outs[slot]
         if mark:
             self.mark(i, 0)
         if self.c_local:
             _ffi.check_status(_ffi.lib().gpu_matrix_mul(self.out.raw, self.a.raw, self.b.raw), "gpu_matrix_mul")
         if mark:
             self.mark(i, 1)
-        self.gather_enqueue(i, slot, self.out if self.c_local else self.out.slice_columns(0, 0))
+        if per_step:
+            self.gather_enqueue(i, slot, self.out if self.c_local else self.out.slice_columns(0, 0))
+        self._ungathered = True
+
+    def drain(self):
+        if self.gather is not None and self.lazy_gather:
+            if self._ungathered:  # the region's one exchange step
+                self.full = self.gather.gather(self.out if self.c_local else self.out.slice_columns(0, 0))
+                self._ungathered = False
+            return
+        super().drain()
 
     def check(self):
         """size-independent property on the timed operands: (A*B) == columns of A*[B] recomputed entry-wise
