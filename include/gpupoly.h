@@ -150,6 +150,11 @@ int gpu_poly_load_compact_bytes(GpuMatrix *poly, const uint8_t *payload, size_t 
  * memory allows, then one product into `out`.  The EVAL-form digit matrix IS written once and read once (a full
  * fusion would need 8 x 16384 accumulators per workgroup).                          */
 int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);
+/* outs[i] = lhss[i] * rhss[i], i < count: independent products of one context and level (all EVAL) in one call.  Small
+ * products - a level of circuit gates on a small ring, where every product is a launch-latency-bound kernel - go out
+ * up to 64 per launch; large ones run one by one through the tuned kernels.  No output may be another product's
+ * operand.  (the reference issues one call per gate, src/circuit/poly_circuit/eval.rs:269.)        */
+int gpupoly_matrix_mul_batch(GpuMatrix *const *outs, const GpuMatrix *const *lhss, const GpuMatrix *const *rhss, size_t count);
 /* lhs * small-G^-1(rhs) (digits of limb 0 only): replaces the column-chunk loop of mul_decompose_small
  * (src/matrix/gpu_dcrt_poly.rs:1495-1574).                                                                */
 int gpupoly_matrix_mul_decompose_small(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);

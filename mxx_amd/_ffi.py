@@ -94,6 +94,7 @@ SIGNATURES = {
     "gpu_poly_store_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(_sz)]),
     "gpu_poly_load_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.c_uint16]),
     "gpupoly_matrix_mul_decompose": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "gpupoly_matrix_mul_batch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t]),
     "gpupoly_matrix_mul_decompose_small": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
     "gpupoly_matrix_mul_tensor_identity": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "gpupoly_matrix_mul_tensor_identity_decompose": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32]),

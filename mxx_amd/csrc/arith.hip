@@ -756,6 +756,132 @@ extern "C" int gpupoly_matrix_mul_tensor_identity_decompose(GpuMatrix *out, cons
     ABI_GUARD_END
 }
 
+// ---- a level of small products in one launch (extension) -----------------------------------------
+// The reference evaluates the gates of a circuit level one ABI call each and gets its parallelism from the device
+// count (src/circuit/poly_circuit/eval.rs:269, MXX_CIRCUIT_PARALLEL_GATES = number of GPUs, src/env.rs:31-56).  On the
+// small rings its own tests use (n <= 256) every product is a launch-latency-bound kernel of a few waves; here up
+// to 64 independent products travel in one launch: the descriptors ride in the kernel-argument segment (no device
+// table, no copy), blockIdx.y selects the product, one lane computes one residue of one output entry.
+struct MulBatchItem {
+    void *c;
+    const void *a, *b;
+    uint32_t rows, inner, cols, pad;
+};
+constexpr size_t kMulBatchMax = 64;
+struct MulBatchArgs {
+    MulBatchItem item[kMulBatchMax];
+};
+
+template <typename W>
+__global__ void __launch_bounds__(256)
+    matmul_batch_kernel(MulBatchArgs args, const LimbConst *__restrict__ limbs, uint32_t L, uint32_t logN) {
+    const MulBatchItem it = args.item[blockIdx.y];
+    const size_t total = (static_cast<size_t>(it.rows) * it.cols * L) << logN;
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t N = static_cast<size_t>(1) << logN;
+    const uint32_t i = static_cast<uint32_t>(idx & (N - 1));
+    const size_t t = idx >> logN;
+    const uint32_t limb = static_cast<uint32_t>(t % L);
+    const size_t rc = t / L;
+    const uint32_t r = static_cast<uint32_t>(rc / it.cols), c = static_cast<uint32_t>(rc - static_cast<size_t>(r) * it.cols);
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q);
+    const size_t poly = static_cast<size_t>(L) << logN;
+    const W *pa = static_cast<const W *>(it.a) + static_cast<size_t>(r) * it.inner * poly + (static_cast<size_t>(limb) << logN) + i;
+    const W *pb = static_cast<const W *>(it.b) + static_cast<size_t>(c) * poly + (static_cast<size_t>(limb) << logN) + i;
+    const size_t stride_b = static_cast<size_t>(it.cols) * poly;
+    typename Wide<W>::type acc = 0;
+    uint32_t pending = 0;
+    for (uint32_t k = 0; k < it.inner; ++k) {
+        acc += static_cast<typename Wide<W>::type>(pa[k * poly]) * pb[k * stride_b];
+        if (++pending >= lc.lazy_terms) {
+            pending = 0;
+            if constexpr (sizeof(W) == 4) acc = reduce_u64_sum(acc, q, lc.mu64);
+            else acc = reduce_u128_sum(acc, q, lc.mu, lc.kbits, lc.mu64);
+        }
+    }
+    W out;
+    if constexpr (sizeof(W) == 4) out = reduce_u64_sum(acc, q, lc.mu64);
+    else out = reduce_u128_sum(acc, q, lc.mu, lc.kbits, lc.mu64);
+    static_cast<W *>(it.c)[(static_cast<size_t>(r) * it.cols + c) * poly + (static_cast<size_t>(limb) << logN) + i] = out;
+}
+
+extern "C" int gpupoly_matrix_mul_batch(GpuMatrix *const *outs, const GpuMatrix *const *lhss, const GpuMatrix *const *rhss,
+                                        size_t count) {
+    ABI_GUARD_BEGIN
+    if (count == 0) return 0;
+    if (!outs || !lhss || !rhss) return set_error("gpupoly_matrix_mul_batch: null array");
+    GpuContext *ctx = nullptr;
+    int level = 0;
+    uint64_t max_work = 0;
+    for (size_t p = 0; p < count; ++p) {
+        GpuMatrix *out = outs[p];
+        const GpuMatrix *lhs = lhss[p], *rhs = rhss[p];
+        if (!out || !lhs || !rhs) return set_error("gpupoly_matrix_mul_batch: null matrix");
+        if (p == 0) {
+            ctx = out->ctx;
+            level = out->level;
+        }
+        if (out->ctx != ctx || lhs->ctx != ctx || rhs->ctx != ctx) return set_error("gpupoly_matrix_mul_batch: context mismatch");
+        if (out->level != level || lhs->level != level || rhs->level != level)
+            return set_error("gpupoly_matrix_mul_batch: level mismatch");
+        if (lhs->cols != rhs->rows || out->rows != lhs->rows || out->cols != rhs->cols)
+            return set_error("gpupoly_matrix_mul_batch: shape mismatch");
+        if (lhs->format != GPU_POLY_FORMAT_EVAL || rhs->format != GPU_POLY_FORMAT_EVAL)
+            return set_error("gpupoly_matrix_mul_batch requires Eval format");
+        if (out == lhs || out == rhs) return set_error("gpupoly_matrix_mul_batch: output must not alias an input");
+        for (size_t o = 0; o < count; ++o)  // an output another product reads or writes: the products are unordered
+            if (o != p && (outs[o] == out || lhss[o] == out || rhss[o] == out))
+                return set_error("gpupoly_matrix_mul_batch: an output aliases another product's operand");
+        max_work = std::max<uint64_t>(max_work, static_cast<uint64_t>(lhs->rows) * lhs->cols * rhs->cols * matrix_limbs(out) *
+                                                    static_cast<uint64_t>(ctx->N));
+    }
+    if (ctx_activate(ctx)) return 1;
+    // large products fill the chip by themselves: one by one through the tuned kernels
+    if (max_work > (1ull << 24)) {
+        for (size_t p = 0; p < count; ++p) {
+            const int rc = gpu_matrix_mul(outs[p], lhss[p], rhss[p]);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    const uint32_t L = static_cast<uint32_t>(level + 1);
+    for (size_t p0 = 0; p0 < count; p0 += kMulBatchMax) {
+        const size_t nb = std::min(kMulBatchMax, count - p0);
+        MulBatchArgs args;
+        size_t max_total = 0, live = 0;
+        for (size_t j = 0; j < nb; ++j) {
+            GpuMatrix *out = outs[p0 + j];
+            out->format = GPU_POLY_FORMAT_EVAL;
+            const size_t total = matrix_polys(out) * L * static_cast<size_t>(ctx->N);
+            if (total == 0) continue;
+            if (lhss[p0 + j]->cols == 0) {
+                HIP_TRY(hipMemsetAsync(out->data, 0, out->bytes, ctx->stream));
+                continue;
+            }
+            MulBatchItem &it = args.item[live++];
+            it.c = out->data;
+            it.a = lhss[p0 + j]->data;
+            it.b = rhss[p0 + j]->data;
+            it.rows = static_cast<uint32_t>(out->rows);
+            it.inner = static_cast<uint32_t>(lhss[p0 + j]->cols);
+            it.cols = static_cast<uint32_t>(out->cols);
+            it.pad = 0;
+            max_total = std::max(max_total, total);
+        }
+        if (live == 0) continue;
+        const dim3 grid(static_cast<unsigned>((max_total + 255) / 256), static_cast<unsigned>(live));
+        if (ctx->wide)
+            hipLaunchKernelGGL(matmul_batch_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, L, ctx->logN);
+        else
+            hipLaunchKernelGGL(matmul_batch_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, L, ctx->logN);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+    ABI_GUARD_END
+}
+
 extern "C" int gpu_matrix_equal(const GpuMatrix *lhs, const GpuMatrix *rhs, int *out_equal) {
     ABI_GUARD_BEGIN
     if (!out_equal) return set_error("gpu_matrix_equal: null out_equal");

@@ -625,6 +625,24 @@ class GpuDCRTPolyMatrix:
         check_status(st, "gpu_matrix_fill_small_decomposed_identity_chunk")
         return out
 
+    @staticmethod
+    def mul_batch(lhss, rhss) -> list:
+        """[l * r for l, r in zip(lhss, rhss)] through `gpupoly_matrix_mul_batch`: the independent products of one
+        circuit level in one call (small ones in one launch; src/circuit/poly_circuit/eval.rs:269 issues one per gate)."""
+        assert len(lhss) == len(rhss)
+        if not lhss:
+            return []
+        ls = [m.ensure_eval() for m in lhss]  # converted copies stay referenced until the call returns
+        rs = [m.ensure_eval() for m in rhss]
+        outs = []
+        for l_, r_ in zip(ls, rs):
+            assert l_.params == r_.params and l_.level == r_.level and l_.ncol == r_.nrow, "mul_batch: operand mismatch"
+            outs.append(GpuDCRTPolyMatrix(l_.params, l_.nrow, r_.ncol, l_.level, True))
+        arr = lambda ms: (C.c_void_p * len(ms))(*[m.raw.value if hasattr(m.raw, "value") else m.raw for m in ms])
+        st = _ffi.lib().gpupoly_matrix_mul_batch(arr(outs), arr(ls), arr(rs), len(outs))
+        check_status(st, "gpupoly_matrix_mul_batch")
+        return outs
+
     def mul_tensor_identity(self, other, identity_size) -> "GpuDCRTPolyMatrix":
         """self * (I (x) other) (gpu_dcrt_poly.rs:1374-1390): one extension call, products written in place."""
         assert self.ncol == other.nrow * identity_size

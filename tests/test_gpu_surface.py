@@ -407,3 +407,44 @@ def test_add_rows_extension(gpu, oracle):
     ga, gb = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True), gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
     with pytest.raises(gpu.GpuPolyError):  # rows 4..5 of a 5-row matrix
         _ffi.check_status(_ffi.lib().gpupoly_matrix_add_rows(out.raw, 4, ga.raw, gb.raw), "gpupoly_matrix_add_rows")
+
+
+@pytest.mark.parametrize("n,depth,bits", [(64, 3, 24), (256, 3, 51), (8, 2, 31)])
+def test_mul_batch_extension(gpu, oracle, n, depth, bits):
+    """gpupoly_matrix_mul_batch: a level's independent products in one call - mixed shapes, more than one launch's worth
+    (70 > 64), 31-bit primes (accumulators folded inside the loop), 64-bit words; every product equals the single call."""
+    p = make_params(gpu, oracle, n, depth, bits, 4)
+    moduli = p.moduli()
+    shapes = [(1, 5, 3), (2, 9, 4), (3, 1, 1), (1, 40, 2), (4, 4, 4)]
+    lhss, rhss = [], []
+    for i in range(70):
+        r, k, c = shapes[i % len(shapes)]
+        lhss.append(gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 600 + i, r, k, moduli, n), True))
+        rhss.append(gpu.GpuDCRTPolyMatrix.from_rns(p, rand_matrix(oracle, 700 + i, k, c, moduli, n), i % 2 == 0))
+    outs = gpu.GpuDCRTPolyMatrix.mul_batch(lhss, rhss)
+    assert len(outs) == 70
+    for l_, r_, o in zip(lhss, rhss, outs):
+        assert o.is_ntt and o == l_ * r_.ensure_eval()
+    # against the CPU restatement too (first few)
+    for i in range(3):
+        want = oracle.matmul(lhss[i].to_rns(), rhss[i].ensure_eval().to_rns(), moduli)
+        assert np.array_equal(outs[i].to_rns(), want)
+    assert gpu.GpuDCRTPolyMatrix.mul_batch([], []) == []
+
+
+def test_mul_batch_large_products_and_errors(gpu, oracle):
+    """products too large for the grouped launch run one by one through the tuned kernels; an output that is another
+    product's operand is refused (the products of a batch are unordered)."""
+    from mxx_amd import _ffi
+    import ctypes as C
+
+    p = make_params(gpu, oracle, 16384, 2, 24, 12)
+    us = gpu.GpuDCRTPolyUniformSampler()
+    a = [us.sample_uniform(p, 2, 6, gpu.DistType.FinRingDist()) for _ in range(3)]
+    b = [us.sample_uniform(p, 6, 5, gpu.DistType.FinRingDist()) for _ in range(3)]
+    for o, l_, r_ in zip(gpu.GpuDCRTPolyMatrix.mul_batch(a, b), a, b):
+        assert o == l_ * r_
+    sq = [us.sample_uniform(p, 2, 2, gpu.DistType.FinRingDist()) for _ in range(3)]
+    arr = lambda ms: (C.c_void_p * len(ms))(*[m.raw.value for m in ms])
+    st = _ffi.lib().gpupoly_matrix_mul_batch(arr([sq[2], sq[0]]), arr([sq[0], sq[1]]), arr([sq[1], sq[2]]), 2)
+    assert st != 0 and "aliases" in _ffi.last_error_string()

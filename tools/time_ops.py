@@ -55,3 +55,13 @@ if which == "tensor":
     print("sample_hash(...).decompose() 8x8 (two calls): %.2f ms" % timed(ctx, lambda: hs.sample_hash(p, key, b"t", 8, 8, d).decompose()))
     M = us.sample_uniform(p, 30, 120, d)
     print("transpose 30x120: %.3f ms" % timed(ctx, lambda: M.transpose()))
+if which == "batch":
+    # a "level" of 16 small products on the M4 ring (n = 256, 51-bit, L = 12): one call per product vs one batched call
+    p = mx.GpuDCRTPolyParams(256, mx.gen_crt_basis(256, 12, 51), 17)
+    us = mx.GpuDCRTPolyUniformSampler()
+    ctx = p.ctx()
+    d = mx.DistType.FinRingDist()
+    ls = [us.sample_uniform(p, 1, 76, d) for _ in range(16)]
+    rs = [us.sample_uniform(p, 76, 4, d) for _ in range(16)]
+    print("16 x (1x76)*(76x4), n=256, L=12: one call each %.3f ms" % timed(ctx, lambda: [l * r for l, r in zip(ls, rs)], 5))
+    print("16 x (1x76)*(76x4): gpupoly_matrix_mul_batch %.3f ms" % timed(ctx, lambda: mx.GpuDCRTPolyMatrix.mul_batch(ls, rs), 5))
