@@ -434,19 +434,28 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
             const int rc = launch_matmul_mfma_u32(out, lhs, rhs);
             if (rc >= 0) return rc;
         }
-        // 32 slots x 32x32 tile, 16 waves (a third less operand traffic per MAC, four-stage ring): wins when it
-        // wastes no more tile area than the 64-slot 32x16 kernel (64^3: 2.15 against 2.43 ms)
-        const bool want_wide = force ? (force == 'w') : (rows >= 32 && cols >= 32 && ((cols + 31) / 32) * 2 <= (cols + 15) / 16);
+        // Shape rules from a sweep of 200 shapes against every forced family (tools/sweep_mm.py, profiles/r02_notes.md):
+        // 32-row tiles (the two streamed kernels) when the last row tile is at least three quarters full; of the two,
+        // the 32 slots x 32x32 tile with 16 waves (a third less operand traffic per MAC, four-stage ring) when it
+        // wastes no more tile area than the 64-slot 32x16 kernel (64^3: 2.15 against 2.43 ms).
+        const size_t inner = lhs->cols;
+        const bool narrow = cols < 16 && inner < 128;  // a few short columns: the register tile wins at every row count
+        const bool rows32 = !narrow && rows >= 24 && (rows % 32 == 0 || rows % 32 >= 24);
+        const bool want_wide = force ? (force == 'w') : (rows32 && cols >= 32 && ((cols + 31) / 32) * 2 <= (cols + 15) / 16);
         if (want_wide) {
             const int rc = launch_matmul_dma32_u32(out, lhs, rhs);
             if (rc >= 0) return rc;
         }
-        const bool want_dma = force ? (force == 'd' || force == 'w') : (rows >= 32 && cols >= 16);
+        const bool want_dma = force ? (force == 'd' || force == 'w') : (rows32 && cols >= 16);
         if (want_dma) {
             const int rc = launch_matmul_dma_u32(out, lhs, rhs);
             if (rc >= 0) return rc;
         }
-        const bool want_lds = force ? (force == 'l' || force == 'd' || force == 'w') : (rows >= 9 && cols >= 8);
+        // few rows: the register-tiled kernel streams B once, but with 4 slots per lane a product with few columns
+        // leaves most CUs idle ((1 x 256)(256 x 8): 64 workgroups, 0.90 ms against 0.24 for the 64-slot LDS tile)
+        const uint64_t reg_lanes = static_cast<uint64_t>(rows >= 4 ? N : N / 4) * ((rows + 7) / 8) * ((cols + 7) / 8) * matrix_limbs(out);
+        const bool thin = cols >= 8 && ((rows == 1 && reg_lanes <= 1024ull * 2 * 64) || (rows <= 3 && reg_lanes <= 32768 && inner >= 64));
+        const bool want_lds = force ? (force == 'l' || force == 'd' || force == 'w') : ((rows >= 9 && cols >= 8 && !narrow) || thin);
         if (lds_ok && want_lds) return launch_matmul_lds_u32(out, lhs, rhs);
     }
     if (N >= 4) {
