@@ -181,6 +181,8 @@ int gpupoly_matrix_tensor(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix 
  * the row-major layout) instead of a copy_block followed by an add_block; used by the preimage's final assembly
  * (src/sampler/trapdoor/gpu.rs:340-369).  The whole destination takes the operands' format tag.            */
 int gpupoly_matrix_add_rows(GpuMatrix *out, size_t dst_row, const GpuMatrix *lhs, const GpuMatrix *rhs);
+/* out = -src in one pass (the reference's wrapper: upload zeros, clone, subtract - gpu_dcrt_poly.rs:1890-1897). */
+int gpupoly_matrix_neg(GpuMatrix *out, const GpuMatrix *src);
 int gpupoly_matrix_fill_zero(GpuMatrix *out);
 int gpupoly_matrix_fill_identity(GpuMatrix *out, const GpuMatrix *scalar_1x1);
 /* G^-1 of a freshly sampled rows x cols matrix: out is (rows*k) x cols, k = digits per entry (small != 0: the digits

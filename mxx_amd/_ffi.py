@@ -102,6 +102,7 @@ SIGNATURES = {
     "gpupoly_matrix_transpose": (C.c_int, [_vp, _vp]),
     "gpupoly_matrix_tensor": (C.c_int, [_vp, _vp, _vp]),
     "gpupoly_matrix_add_rows": (C.c_int, [_vp, C.c_size_t, _vp, _vp]),
+    "gpupoly_matrix_neg": (C.c_int, [_vp, _vp]),
     "gpupoly_matrix_fill_zero": (C.c_int, [_vp]),
     "gpupoly_matrix_fill_identity": (C.c_int, [_vp, _vp]),
     "gpupoly_matrix_sample_decomposed": (C.c_int, [_vp, C.c_int, C.c_double, GpuRngSeed, C.c_uint32, C.c_int]),

@@ -15,7 +15,7 @@
 
 #include <algorithm>
 
-enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_NEG = 3 };
 
 template <typename W, int OP, bool BCAST, int VN>
 __global__ void elementwise_kernel(W *__restrict__ out, const W *__restrict__ a, const W *__restrict__ b,
@@ -42,6 +42,7 @@ __global__ void elementwise_kernel(W *__restrict__ out, const W *__restrict__ a,
         for (int j = 0; j < VN; ++j) {
             if (OP == OP_ADD) ov[j] = add_mod<W>(av[j], bv[j], q);
             else if (OP == OP_SUB) ov[j] = sub_mod<W>(av[j], bv[j], q);
+            else if (OP == OP_NEG) ov[j] = bv[j] ? static_cast<W>(q - bv[j]) : static_cast<W>(0);
             else ov[j] = mul_mod<W>(av[j], bv[j], q, lc.mu, lc.kbits);
         }
         if (VN == 1) {
@@ -87,13 +88,18 @@ __global__ void tensor_kernel(W *__restrict__ out, const W *__restrict__ a, cons
     }
 }
 
+// one atomic per wave that saw a difference, and nothing more once the flag is up (with every lane of 8192 blocks
+// reporting its own difference, comparing two unequal 13 MB matrices took 0.4 ms of serialised atomics)
 template <typename W>
 __global__ void equal_kernel(const W *__restrict__ a, const W *__restrict__ b, size_t total, int *__restrict__ diff) {
     size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     int d = 0;
-    for (; i < total; i += stride) d |= (a[i] != b[i]);
-    if (d) atomicOr(diff, 1);
+    for (; i < total; i += stride) {
+        d |= (a[i] != b[i]);
+        if (__any(d)) break;
+    }
+    if (__any(d) && (threadIdx.x & 63u) == 0 && *reinterpret_cast<volatile int *>(diff) == 0) atomicOr(diff, 1);
 }
 
 // ---- matrix product ---------------------------------------------------------------------
@@ -559,6 +565,18 @@ extern "C" int gpu_matrix_sub(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
     int rc = launch_elementwise<OP_SUB, false>(out, lhs, rhs);
     if (rc) return rc;
     out->format = rhs->format;  // see gpu_matrix_add
+    return 0;
+    ABI_GUARD_END
+}
+
+// Extension: out = -src in one pass.  The reference's wrapper uploads a host vector of zeros, clones it and subtracts
+// (src/matrix/gpu_dcrt_poly.rs:1890-1897): a PCIe transfer and five passes for a sign change.  out may be src.
+extern "C" int gpupoly_matrix_neg(GpuMatrix *out, const GpuMatrix *src) {
+    ABI_GUARD_BEGIN
+    if (matrix_check_same_shape(out, src, "gpupoly_matrix_neg")) return 1;
+    int rc = launch_elementwise<OP_NEG, false>(out, src, src);
+    if (rc) return rc;
+    out->format = src->format;
     return 0;
     ABI_GUARD_END
 }

@@ -515,20 +515,30 @@ class GpuDCRTPolyMatrix:
         check_status(_ffi.lib().gpu_matrix_sub(self.raw, self.raw, rhs.raw), "gpu_matrix_sub")
         self.is_ntt = rhs.is_ntt
 
-    def __add__(self, rhs):
-        out = self.clone()
-        out.add_in_place(rhs)
+    def _binop(self, rhs, fn, what):
+        """out = self (+|-) rhs through the three-operand ABI call into a fresh matrix: three passes over memory.  The
+        reference's `&a + &b` clones a and adds in place (gpu_dcrt_poly.rs:1731-1739): five passes."""
+        self._check_binop(rhs, what)
+        out = GpuDCRTPolyMatrix(self.params, self.nrow, self.ncol, self.level, self.is_ntt)
+        if self.nrow == 0 or self.ncol == 0:
+            return out
+        check_status(fn(out.raw, self.raw, rhs.raw), what)
+        out.is_ntt = rhs.is_ntt
         return out
+
+    def __add__(self, rhs):
+        return self._binop(rhs, _ffi.lib().gpu_matrix_add, "gpu_matrix_add")
 
     def __sub__(self, rhs):
-        out = self.clone()
-        out.sub_in_place(rhs)
-        return out
+        return self._binop(rhs, _ffi.lib().gpu_matrix_sub, "gpu_matrix_sub")
 
     def __neg__(self):
-        z = GpuDCRTPolyMatrix._new_zero_with_state(self.params, self.nrow, self.ncol, self.level, self.is_ntt)
-        z.sub_in_place(self)
-        return z
+        """one pass (gpupoly_matrix_neg); the reference uploads zeros, clones and subtracts (gpu_dcrt_poly.rs:1890-1897)"""
+        out = GpuDCRTPolyMatrix(self.params, self.nrow, self.ncol, self.level, self.is_ntt)
+        if self.nrow == 0 or self.ncol == 0:
+            return out
+        check_status(_ffi.lib().gpupoly_matrix_neg(out.raw, self.raw), "gpupoly_matrix_neg")
+        return out
 
     def mul_scalar(self, scalar) -> "GpuDCRTPolyMatrix":
         """`mul_scalar` (gpu_dcrt_poly.rs:1770-1790)."""

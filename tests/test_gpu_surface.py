@@ -448,3 +448,26 @@ def test_mul_batch_large_products_and_errors(gpu, oracle):
     arr = lambda ms: (C.c_void_p * len(ms))(*[m.raw.value for m in ms])
     st = _ffi.lib().gpupoly_matrix_mul_batch(arr([sq[2], sq[0]]), arr([sq[0], sq[1]]), arr([sq[1], sq[2]]), 2)
     assert st != 0 and "aliases" in _ffi.last_error_string()
+
+
+@pytest.mark.parametrize("n,depth,bits", [(4, 2, 17), (256, 3, 24), (64, 2, 51)])
+def test_neg_extension_and_three_operand_add_sub(gpu, oracle, n, depth, bits):
+    """gpupoly_matrix_neg (one pass, also in place) and the wrapper's a + b / a - b through the three-operand ABI call
+    into a fresh matrix, against the CPU restatement; zero residues stay zero under negation."""
+    from mxx_amd import _ffi
+
+    p = make_params(gpu, oracle, n, depth, bits, 4)
+    moduli = p.moduli()
+    a, b = rand_matrix(oracle, 801, 2, 3, moduli, n), rand_matrix(oracle, 802, 2, 3, moduli, n)
+    a[0, 0, :, :2] = 0
+    zero = np.zeros_like(a)
+    for fmt in (True, False):
+        ga, gb = gpu.GpuDCRTPolyMatrix.from_rns(p, a, fmt), gpu.GpuDCRTPolyMatrix.from_rns(p, b, fmt)
+        neg = -ga
+        assert neg.is_ntt == fmt and np.array_equal(neg.to_rns(), oracle.pointwise("sub", zero, a, moduli))
+        assert np.array_equal((ga + gb).to_rns(), oracle.pointwise("add", a, b, moduli))
+        assert np.array_equal((ga - gb).to_rns(), oracle.pointwise("sub", a, b, moduli))
+        assert np.array_equal(ga.to_rns(), a) and np.array_equal(gb.to_rns(), b)  # operands untouched
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_neg(ga.raw, ga.raw), "gpupoly_matrix_neg")  # in place
+        assert ga == neg
+    assert not (gpu.GpuDCRTPolyMatrix.from_rns(p, a, True) == gpu.GpuDCRTPolyMatrix.from_rns(p, b, True))
