@@ -83,33 +83,48 @@ __host__ __device__ constexpr int gs_exp_after(int u, int j) {
     return e;
 }
 
+// one stage (bit HB of the element index) of the pass; a function template per stage, because the optimiser gives up
+// unrolling the stage loop of the 32-element passes for some instantiations (64-bit words; 2^13 and 2^15 points) -
+// the element array then lives in scratch memory and the inverse transform runs 2-5x slower than the forward one
+template <typename W, int C, bool LAST, int K>
+__device__ __forceinline__ void gs_stage_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p, W q,
+                                              const LimbConst &lc) {
+    constexpr int hb = C - K - 1;  // bit used by this stage
+    constexpr int half = 1 << hb;
+    const uint32_t tb = (1u << (s_p + K)) + (bi << K);
+#pragma unroll
+    for (int u = 0; u < (1 << C); ++u) {
+        if (u & half) continue;
+        const int e_in = hb == 0 ? 1 : gs_exp_after(u, hb - 1);  // same for u and u+half
+        const W M = q << e_in;                                  // bound of Y
+        const W X = v[u], Y = v[u + half];
+        const W D = X + M - Y;
+        if (LAST && K == 0) {
+            // last stage of the whole transform: fold N^-1 into both outputs
+            const W A = X + Y, nq = opaque_neg<W>(q);
+            v[u] = A * static_cast<W>(lc.n_inv) + mulhi_w(A, static_cast<W>(lc.n_inv_sh)) * nq;
+            v[u + half] = D * static_cast<W>(lc.inv_last_w) + mulhi_w(D, static_cast<W>(lc.inv_last_w_sh)) * nq;
+        } else {
+            const TwPair<W> t = tw[tb + (static_cast<uint32_t>(u) >> (C - K))];
+            v[u] = X + Y;
+            v[u + half] = D * t.w + mulhi_w(D, t.ws) * opaque_neg<W>(q);  // [0, 2q); multiply-add form
+        }
+    }
+}
+
+template <typename W, int C, bool LAST, int K>
+struct GsStages {
+    static __device__ __forceinline__ void run(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p, W q,
+                                               const LimbConst &lc) {
+        gs_stage_lazy<W, C, LAST, K>(v, tw, bi, s_p, q, lc);
+        if constexpr (K > 0) GsStages<W, C, LAST, K - 1>::run(v, tw, bi, s_p, q, lc);
+    }
+};
+
 template <typename W, int C, bool LAST>
 __device__ __forceinline__ void gs_network_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p,
                                                 W q, const LimbConst &lc) {
-#pragma unroll
-    for (int k = C - 1; k >= 0; --k) {
-        const int hb = C - k - 1;  // bit used by this stage
-        const int half = 1 << hb;
-        const uint32_t tb = (1u << (s_p + k)) + (bi << k);
-#pragma unroll
-        for (int u = 0; u < (1 << C); ++u) {
-            if (u & half) continue;
-            const int e_in = hb == 0 ? 1 : gs_exp_after(u, hb - 1);  // same for u and u+half
-            const W M = q << e_in;                                  // bound of Y
-            const W X = v[u], Y = v[u + half];
-            const W D = X + M - Y;
-            if (LAST && k == 0) {
-                // last stage of the whole transform: fold N^-1 into both outputs
-                const W A = X + Y, nq = opaque_neg<W>(q);
-                v[u] = A * static_cast<W>(lc.n_inv) + mulhi_w(A, static_cast<W>(lc.n_inv_sh)) * nq;
-                v[u + half] = D * static_cast<W>(lc.inv_last_w) + mulhi_w(D, static_cast<W>(lc.inv_last_w_sh)) * nq;
-            } else {
-                const TwPair<W> t = tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
-                v[u] = X + Y;
-                v[u + half] = D * t.w + mulhi_w(D, t.ws) * opaque_neg<W>(q);  // [0, 2q); multiply-add form
-            }
-        }
-    }
+    GsStages<W, C, LAST, C - 1>::run(v, tw, bi, s_p, q, lc);  // stages K = C-1 .. 0
 }
 
 // bring every element of a finished inverse pass back to [0, 2q)
