@@ -217,7 +217,10 @@ __device__ __forceinline__ void lds_set_addr(uint32_t tid, int g, uint32_t &bi, 
     pbase = lds_pad_c(bi * B + r);
 }
 
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU>
+// PRE > 0: the vector has 2^(LOGN + PRE) points and its first PRE stages were done by ntt_fwd_head_kernel; what is
+// left are 2^PRE independent 2^LOGN-point sub-transforms (one workgroup each) whose twiddles sit at stage PRE + s,
+// block (sub << s) + b of the full ring's table.
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                         uint32_t L) {
@@ -228,17 +231,18 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
     const uint32_t tid = threadIdx.x;
-    const size_t vec = blockIdx.x;
+    const size_t vec = blockIdx.x >> PRE;
+    const uint32_t sub = blockIdx.x & ((1u << PRE) - 1u);
     const uint32_t limb = static_cast<uint32_t>(vec % L);
     const LimbConst lc = limbs[limb];
     const W q = static_cast<W>(lc.q), twoq = q + q;
-    const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
-    W *g = data + vec * N;
+    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << (LOGN + PRE));
+    W *g = data + (vec << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
     {   // pass 0: stages [0, LOGR), elements tid + T*u straight from HBM (coalesced per u)
         W v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = g[tid + T * u];
-        ct_network_lazy<W, LOGR>(v, tw, 0, 0, q, twoq);
+        ct_network_lazy<W, LOGR>(v, tw, sub, PRE, q, twoq);
         const uint32_t pb = lds_pad_c(tid);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(T * u)] = v[u];
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         W v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
-        ct_network_lazy<W, LOGR>(v, tw, bi, LOGR, q, twoq);
+        ct_network_lazy<W, LOGR>(v, tw, (sub << LOGR) + bi, PRE + LOGR, q, twoq);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = v[u];
     }
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
             W v[E];
 #pragma unroll
             for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
-            ct_network_lazy<W, CLAST>(v, tw, tid * G + gi, 2 * LOGR, q, twoq);
+            ct_network_lazy<W, CLAST>(v, tw, (sub << (2 * LOGR)) + tid * G + gi, PRE + 2 * LOGR, q, twoq);
             // canonical form: values < (1 + 2 logN) q
 #pragma unroll
             for (int u = 0; u < E; ++u) x[pb0 + gi * E + u] = csub<W>(fold_2q<W>(v[u], q, muw), q);
@@ -282,7 +286,8 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     }
 }
 
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU>
+// PRE > 0: the last PRE stages (and the N^-1 scaling) are left to ntt_inv_tail_kernel; outputs stay below 2q
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_inv_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                         uint32_t L) {
@@ -293,13 +298,14 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
     const uint32_t tid = threadIdx.x;
-    const size_t vec = blockIdx.x;
+    const size_t vec = blockIdx.x >> PRE;
+    const uint32_t sub = blockIdx.x & ((1u << PRE) - 1u);
     const uint32_t limb = static_cast<uint32_t>(vec % L);
     const LimbConst lc = limbs[limb];
     const W q = static_cast<W>(lc.q);
     const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
-    const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
-    W *g = data + vec * N;
+    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << (LOGN + PRE));
+    W *g = data + (vec << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
 
     // HBM -> LDS, 16 bytes per lane
     typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
@@ -318,7 +324,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
             W v[E];
 #pragma unroll
             for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
-            gs_network_lazy<W, CLAST, false>(v, tw, tid * G + gi, 2 * LOGR, q, lc);
+            gs_network_lazy<W, CLAST, false>(v, tw, (sub << (2 * LOGR)) + tid * G + gi, PRE + 2 * LOGR, q, lc);
             gs_fold<W, CLAST>(v, q, muw);
 #pragma unroll
             for (int u = 0; u < E; ++u) x[pb0 + gi * E + u] = v[u];
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         W v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
-        gs_network_lazy<W, LOGR, false>(v, tw, bi, LOGR, q, lc);
+        gs_network_lazy<W, LOGR, false>(v, tw, (sub << LOGR) + bi, PRE + LOGR, q, lc);
         gs_fold<W, LOGR>(v, q, muw);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = v[u];
@@ -343,10 +349,66 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         W v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(T * u)];
-        gs_network_lazy<W, LOGR, true>(v, tw, 0, 0, q, lc);
-        // elements that did not go through the N^-1 Shoup product of the last stage carry
-        // A-path bounds from the earlier stages of this pass; those that did are < 2q
+        if constexpr (PRE == 0) {
+            gs_network_lazy<W, LOGR, true>(v, tw, 0, 0, q, lc);
+            // elements that did not go through the N^-1 Shoup product of the last stage carry
+            // A-path bounds from the earlier stages of this pass; those that did are < 2q
 #pragma unroll
-        for (int u = 0; u < R; ++u) g[tid + T * u] = csub<W>(v[u], q);
+            for (int u = 0; u < R; ++u) g[tid + T * u] = csub<W>(v[u], q);
+        } else {
+            gs_network_lazy<W, LOGR, false>(v, tw, sub, PRE, q, lc);
+            gs_fold<W, LOGR>(v, q, muw);  // below 2q: the input bound of the tail kernel's butterflies
+#pragma unroll
+            for (int u = 0; u < R; ++u) g[tid + T * u] = v[u];
+        }
     }
+}
+
+
+// ---- rings too large for LDS (2^16, 2^17 points; 64-bit words from 2^15): two kernels, two HBM round trips ----------
+// Head: stages [0, PRE) on the strided sets {j + (N >> PRE) u}; afterwards the vector is 2^PRE independent sub-vectors,
+// which ntt_fwd_lazy_kernel<.., PRE> transforms in LDS.  The inverse mirrors it: sub-vectors first (outputs below 2q),
+// then the tail below with the N^-1 scaling.  (One launch per stage, 16-17 round trips, ran at 0.3-0.4 TB/s.)
+template <typename W, int PRE>
+__global__ void __launch_bounds__(256)
+    ntt_fwd_head_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+                        uint32_t L, uint32_t logN) {
+    constexpr int R = 1 << PRE;
+    const uint32_t S = (1u << logN) >> PRE;                   // stride between the elements of a set
+    const uint32_t sets_blocks = S / blockDim.x;              // workgroups per vector
+    const size_t vec = blockIdx.x / sets_blocks;
+    const uint32_t j = (blockIdx.x - static_cast<uint32_t>(vec) * sets_blocks) * blockDim.x + threadIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q), twoq = q + q;
+    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << logN);
+    W *g = data + (vec << logN) + j;
+    W v[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] = g[static_cast<size_t>(S) * u];
+    ct_network_lazy<W, PRE>(v, tw, 0, 0, q, twoq);
+#pragma unroll
+    for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = v[u];
+}
+
+template <typename W, int PRE>
+__global__ void __launch_bounds__(256)
+    ntt_inv_tail_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+                        uint32_t L, uint32_t logN) {
+    constexpr int R = 1 << PRE;
+    const uint32_t S = (1u << logN) >> PRE;
+    const uint32_t sets_blocks = S / blockDim.x;
+    const size_t vec = blockIdx.x / sets_blocks;
+    const uint32_t j = (blockIdx.x - static_cast<uint32_t>(vec) * sets_blocks) * blockDim.x + threadIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q);
+    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << logN);
+    W *g = data + (vec << logN) + j;
+    W v[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] = g[static_cast<size_t>(S) * u];
+    gs_network_lazy<W, PRE, true>(v, tw, 0, 0, q, lc);
+#pragma unroll
+    for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = csub<W>(v[u], q);
 }

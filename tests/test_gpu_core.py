@@ -526,7 +526,7 @@ def test_maximum_limb_count(gpu, oracle):
 
 @pytest.mark.parametrize("logn", [15, 16, 17])
 def test_ntt_large_ring_dimensions(gpu, oracle, logn):
-    """n = 2^15 (largest LDS-resident kernel), 2^16 and 2^17 (one-stage-per-launch kernels; 2^17 is the limit)."""
+    """n = 2^15 (largest LDS-resident kernel), 2^16 and 2^17 (head / tail kernel + LDS sub-transforms; 2^17 is the limit)."""
     n = 1 << logn
     moduli = oracle.gen_crt_basis(n, 2, 24)
     p = gpu.GpuDCRTPolyParams(n, moduli, 12)
@@ -547,3 +547,29 @@ def test_ntt_large_ring_dimensions(gpu, oracle, logn):
     g = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 1, 1, oracle.DIST["gauss"], 7.5, gpu.GpuRngSeed.from_bytes(sd))
     assert np.array_equal(g.to_coeff_rns(), oracle.sample_distribution(1, 1, moduli, n, "gauss", 7.5, sd))
     assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, gy.to_compact_bytes()) == gy
+
+
+@pytest.mark.parametrize("logn,bits", [(15, 51), (16, 51), (17, 51), (16, 24), (17, 24)])
+def test_ntt_beyond_lds_split_kernels_equal_the_per_stage_path(gpu, oracle, hip_env, logn, bits):
+    """Rings whose vectors do not fit LDS (u32 from 2^16 points, u64 from 2^15): the two-kernel transform (outer stages
+    on strided sets + LDS kernel on the sub-vectors) against the oracle and against the one-launch-per-stage kernels
+    (MXX_HIP_NTT_PATH=global), both directions, extreme inputs included."""
+    n = 1 << logn
+    moduli = oracle.gen_crt_basis(n, 2, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 12)
+    x = rand_matrix(oracle, 99, 2, 1, moduli, n)
+    x[0, 0, :, :4] = 0
+    x[1, 0, :, -4:] = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(-1, 1)
+    want = oracle.matrix_ntt(x, moduli)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), want)
+    hip_env.set("MXX_HIP_NTT_PATH", "global")
+    g = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    g.ntt_all_in_place()
+    assert g == m
+    g.intt_all_in_place()
+    assert np.array_equal(g.to_rns(), x)
+    hip_env.unset("MXX_HIP_NTT_PATH")
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
