@@ -116,3 +116,72 @@ def test_column_all_gather_is_ordered_on_the_device_world1(gpu, tmp_path):
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "RCCL_PIPELINED_GATHER_OK" in out.stdout
+
+
+CHILD_UNEVEN = textwrap.dedent(
+    """
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch
+    torch.cuda.set_device(0)
+    import mxx_amd as mx
+    from mxx_amd.parallel import ColumnAllGather, shard_range
+    from oracle import oracle as O
+
+    class Work:
+        def __init__(self, hub): self.hub = hub
+        def wait(self): self.hub.deliver()
+
+    class Hub:
+        # two "ranks" of one process: the collective copies every rank's send buffer into every rank's receive buffer
+        def __init__(self, world): self.world, self.calls = world, {{}}
+        def register(self, rank, recv, send): self.calls[rank] = (recv, send)
+        def deliver(self):
+            if len(self.calls) < self.world: raise RuntimeError("a rank did not start its gather")
+            torch.cuda.synchronize()
+            n = self.calls[0][1].numel()
+            for rank, (recv, _) in self.calls.items():
+                for r in range(self.world):
+                    recv[r * n:(r + 1) * n].copy_(self.calls[r][1])
+            torch.cuda.synchronize()
+
+    class FakeDist:
+        def __init__(self, hub, rank): self.hub, self.rank = hub, rank
+        def get_world_size(self): return self.hub.world
+        def get_rank(self): return self.rank
+        def all_gather_into_tensor(self, recv, send, async_op=False):
+            self.hub.register(self.rank, recv, send)
+            return Work(self.hub)
+
+    n = 1024
+    moduli = O.gen_crt_basis(n, 2, 24)
+    p = mx.GpuDCRTPolyParams(n, moduli, 12)
+    for rows, cols in ((1, 5), (3, 5), (22, 7)):   # 5 columns over 2 ranks: 3 + 2; 7: 4 + 3 (uneven shards, padded blocks)
+        world = 2
+        full = O.random_matrix(400 + rows, rows, cols, moduli, n)
+        hub = Hub(world)
+        gathers, pend = [], []
+        for r in range(world):
+            sr = shard_range(cols, world, r)
+            local = mx.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(full[:, sr.start:sr.stop]), True)
+            g = ColumnAllGather(p, rows, cols, 1, torch, FakeDist(hub, r), 0)
+            gathers.append(g)
+            pend.append(g.start(local))
+        for r in range(world):
+            got = gathers[r].finish(pend[r])
+            assert np.array_equal(got.to_rns(), full), ("rank", r, "rows", rows, "cols", cols)
+    print("UNEVEN_SHARDS_OK")
+    """
+)
+
+
+def test_column_all_gather_uneven_shards_two_ranks_in_one_process(gpu, tmp_path):
+    """The padded path of ColumnAllGather with uneven shards (what ranks see for 50 target columns on 8 GPUs): two
+    ranks simulated in one process with a stand-in for torch.distributed that copies every rank's send buffer into
+    every rank's receive buffer; the staging copy, the placement and the un-padding must rebuild the full matrix."""
+    script = tmp_path / "child_uneven.py"
+    script.write_text(CHILD_UNEVEN.format(root=ROOT))
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "UNEVEN_SHARDS_OK" in out.stdout
