@@ -41,14 +41,30 @@ def test_crt_basis_reference_held_datum():
     assert DCRTPolyParams().to_crt()[0] == [131041, 131009]
 
 
-def test_modulus_bits_consistency():
-    # in-tree consistency checks of the reference: modulus_bits == depth*bits
-    # (src/poly/dcrt/params.rs:118-177)
-    for n, depth, bits in [(16, 4, 51), (16, 7, 20)]:
+def test_reference_params_tests_replayed():
+    """Every case of the reference's own `DCRTPolyParams` tests (src/poly/dcrt/params.rs:116-213), replayed on the
+    host mirror and on the oracle's basis rule: ring dimensions 16 / 2 / 1 with modulus_bits == 204, modulus_bits ==
+    depth * bits for depths 4..6 at 51 bits and depth 7 at 20 bits, base_bits 1 / 4 / 20 kept, and the panic message
+    for a ring dimension that is not a power of two.  These pin the bit length of Q and the basis rule's divisibility
+    (q = 1 mod 2n), not the prime values themselves."""
+    from mxx_amd.params import DCRTPolyParams
+
+    for n in (16, 2, 1):
+        p = DCRTPolyParams(n, 4, 51, 1)
+        assert p.ring_dimension() == n and p.modulus_bits() == 204 and p.base_bits() == 1
+    for depth, bits in ((4, 51), (5, 51), (6, 51), (7, 20)):
+        p = DCRTPolyParams(16, depth, bits, 1)
+        assert p.ring_dimension() == 16 and p.modulus_bits() == depth * bits
+        basis = O.gen_crt_basis(16, depth, bits)
         Q = 1
-        for q in O.gen_crt_basis(n, depth, bits):
+        for q in basis:
             Q *= q
-        assert Q.bit_length() == depth * bits
+            assert (q - 1) % 32 == 0
+        assert Q.bit_length() == depth * bits and p.to_crt()[0] == basis
+    for base in (1, 4, 20):
+        assert DCRTPolyParams(16, 4, 51, base).base_bits() == base
+    with pytest.raises(ValueError, match="ring_dimension must be a power of 2"):
+        DCRTPolyParams(20, 4, 51, 1)
 
 
 @pytest.mark.parametrize("n,bits", [(4, 17), (16, 18), (128, 17), (128, 16), (256, 51), (1024, 51), (4096, 24)])
