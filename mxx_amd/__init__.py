@@ -25,6 +25,16 @@ from .sampler import (  # noqa: F401
     GpuDCRTPolyHashSampler,
     GpuDCRTPolyUniformSampler,
     hash_seed_for_matrix,
+    keccak256,
     random_gpu_rng_seed,
+    sample_gpu_matrix_with_seed,
+    sample_gpu_matrix_with_seed_columns,
 )
-from .trapdoor import GpuDCRTPolyTrapdoorSampler, GpuDCRTTrapdoor  # noqa: F401
+from .trapdoor import (  # noqa: F401
+    GpuDCRTPolyTrapdoorSampler,
+    GpuDCRTTrapdoor,
+    compute_preimage_norm,
+    p1_covariance_parameters,
+    preimage_c,
+    preimage_smoothing_parameter,
+)

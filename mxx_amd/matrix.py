@@ -254,6 +254,49 @@ class GpuDCRTPolyMatrix:
         return backing[start : head_room + plen.value].tobytes()
 
     @classmethod
+    def zero_compact_bytes(cls, params, nrow, ncol, level, is_ntt, max_coeff_bits) -> bytes:
+        """Compact bytes of a zero matrix without touching the device (gpu_dcrt_poly.rs:1681-1710)."""
+        assert level < params.crt_depth(), "invalid level for compact zero matrix"
+        max_coeff_bits = max(int(max_coeff_bits), 1)
+        bytes_per_coeff = -(-max_coeff_bits // 8)
+        coeff_count = nrow * ncol * params.ring_dimension()
+        payload_len = -(-coeff_count * max_coeff_bits // 8)
+        fmt = GPU_POLY_FORMAT_EVAL if is_ntt else GPU_POLY_FORMAT_COEFF
+        header = b"".join([bytes([1, fmt]), _bincode_varint(level), _bincode_varint(nrow), _bincode_varint(ncol),
+                           _bincode_varint(max_coeff_bits), _bincode_varint(bytes_per_coeff), _bincode_varint(payload_len)])
+        return header + bytes(payload_len)
+
+    @classmethod
+    def from_poly_vec(cls, params, rows) -> "GpuDCRTPolyMatrix":
+        """`from_poly_vec` (gpu_dcrt_poly.rs:1092-1115): entries are transformed to EVAL and copied in."""
+        if not rows:
+            return cls.new_empty(params, 0, 0)
+        nrow, ncol = len(rows), len(rows[0])
+        if ncol == 0:
+            return cls.new_empty(params, nrow, 0)
+        first = rows[0][0].inner if hasattr(rows[0][0], "inner") else rows[0][0]
+        out = cls(params, nrow, ncol, first.level, True)
+        for i, row in enumerate(rows):
+            assert len(row) == ncol, "row length mismatch in from_poly_vec"
+            for j, poly in enumerate(row):
+                m = poly.inner if hasattr(poly, "inner") else poly
+                assert m.params == params, "params mismatch in from_poly_vec entry"
+                assert m.level == first.level, "level mismatch in from_poly_vec entry"
+                out.copy_block_from(m.ensure_eval(), i, j, 0, 0, 1, 1)
+        return out
+
+    def modulus_switch(self, new_modulus: int) -> "GpuDCRTPolyMatrix":
+        """`modulus_switch` (gpu_dcrt_poly.rs:1352-1372): a host round trip, as in the reference - every coefficient c
+        becomes floor(c * new_modulus / Q) mod new_modulus (src/element/finite_ring.rs:22-26); params are unchanged."""
+        from .poly import GpuDCRTPoly
+
+        Q = self.params.modulus()
+        rows = []
+        for row in self.coeffs():
+            rows.append([GpuDCRTPoly.from_coeffs(self.params, [(c * new_modulus // Q) % new_modulus for c in poly]) for poly in row])
+        return GpuDCRTPolyMatrix.from_poly_vec(self.params, rows)
+
+    @classmethod
     def from_compact_bytes(cls, params, data: bytes) -> "GpuDCRTPolyMatrix":
         """gpu_dcrt_poly.rs:1004-1044."""
         version, fmt = data[0], data[1]
@@ -652,6 +695,57 @@ class GpuDCRTPolyMatrix:
         st = _ffi.lib().gpupoly_matrix_mul_batch(arr(outs), arr(ls), arr(rs), len(outs))
         check_status(st, "gpupoly_matrix_mul_batch")
         return outs
+
+    # ---- PolyMatrix trait defaults the GPU wrapper inherits (src/matrix/mod.rs:185-345) ------------------------
+    def decompose_chunk(self, chunk_idx, chunk_count) -> "GpuDCRTPolyMatrix":
+        assert chunk_count > 0, "decompose_chunk chunk_count must be > 0"
+        assert chunk_idx < chunk_count, f"decompose_chunk chunk_idx out of range: chunk_idx={chunk_idx}, chunk_count={chunk_count}"
+        full = self.decompose()
+        assert full.nrow == self.nrow * chunk_count, f"decompose_chunk expected decomposed row count {self.nrow * chunk_count} but got {full.nrow}"
+        return full.slice(chunk_idx * self.nrow, (chunk_idx + 1) * self.nrow, 0, self.ncol)
+
+    def small_decompose_chunk(self, chunk_idx, chunk_count) -> "GpuDCRTPolyMatrix":
+        assert chunk_count > 0, "small_decompose_chunk chunk_count must be > 0"
+        assert chunk_idx < chunk_count, f"small_decompose_chunk chunk_idx out of range: chunk_idx={chunk_idx}, chunk_count={chunk_count}"
+        full = self.small_decompose()
+        assert full.nrow == self.nrow * chunk_count, f"small_decompose_chunk expected decomposed row count {self.nrow * chunk_count} but got {full.nrow}"
+        return full.slice(chunk_idx * self.nrow, (chunk_idx + 1) * self.nrow, 0, self.ncol)
+
+    @classmethod
+    def small_decomposed_identity_chunk_from_scalar(cls, params, size, scalar, chunk_idx, chunk_count):
+        """gpu_dcrt_poly.rs:1328-1350: the scalar's small digits, then one fill per chunk."""
+        dec = cls.identity(params, 1, scalar).small_decompose()
+        assert dec.size() == (chunk_count, 1), "scalar small decomposition shape mismatch in small_decomposed_identity_chunk_from_scalar"
+        by_digit = [dec.entry(d, 0) for d in range(chunk_count)]
+        return cls.small_decomposed_identity_chunk(params, size, chunk_idx, chunk_count, by_digit)
+
+    @classmethod
+    def unit_column_vector(cls, params, size, index) -> "GpuDCRTPolyMatrix":
+        from .poly import GpuDCRTPoly
+
+        assert index < size, "unit column index must be in range"
+        col = [[GpuDCRTPoly.const_one(params) if i == index else GpuDCRTPoly.const_zero(params)] for i in range(size)]
+        return cls.from_poly_vec(params, col)
+
+    @classmethod
+    def unit_row_vector(cls, params, size, index) -> "GpuDCRTPolyMatrix":
+        from .poly import GpuDCRTPoly
+
+        row = [GpuDCRTPoly.const_one(params) if j == index else GpuDCRTPoly.const_zero(params) for j in range(size)]
+        return cls.from_poly_vec(params, [row])
+
+    def block_entries(self, rows: range, cols: range) -> list:
+        assert rows.start <= rows.stop <= self.nrow and cols.start <= cols.stop <= self.ncol, "block range out of bounds"
+        return [[self.entry(i, j) for j in cols] for i in rows]
+
+    def concat_rows_owned(self, others) -> "GpuDCRTPolyMatrix":
+        return self.concat_rows(others)
+
+    def concat_columns_owned(self, others) -> "GpuDCRTPolyMatrix":
+        return self.concat_columns(others)
+
+    def concat_diag_owned(self, others) -> "GpuDCRTPolyMatrix":
+        return self.concat_diag(others)
 
     def mul_tensor_identity(self, other, identity_size) -> "GpuDCRTPolyMatrix":
         """self * (I (x) other) (gpu_dcrt_poly.rs:1374-1390): one extension call, products written in place."""

@@ -58,6 +58,7 @@ class GpuDCRTPoly:
         return cls.from_biguints(params, [value])
 
     from_usize_to_constant = from_biguint_to_constant
+    from_elem_to_constant = from_biguint_to_constant  # FinRingElem -> its value (gpu.rs:1021-1023)
 
     @classmethod
     def const_zero(cls, params):
@@ -107,13 +108,59 @@ class GpuDCRTPoly:
         dec = self.inner.decompose()
         return [dec.entry(i, 0) for i in range(dec.nrow)]
 
+    @classmethod
+    def from_decomposed(cls, params, decomposed) -> "GpuDCRTPoly":
+        """sum_i 2^i * decomposed[i] (gpu.rs:941-949)."""
+        acc = cls.const_zero(params)
+        for i, bit_poly in enumerate(decomposed):
+            acc = acc + bit_poly * cls.from_biguint_to_constant(params, 1 << i)
+        return acc
+
+    @classmethod
+    def from_compact_bytes(cls, params, data: bytes) -> "GpuDCRTPoly":
+        """gpu.rs:951-957: the bytes of a 1x1 matrix."""
+        mat = GpuDCRTPolyMatrix.from_compact_bytes(params, data)
+        assert mat.size() == (1, 1), "GpuDCRTPoly compact bytes must decode to 1x1 matrix"
+        return mat.entry(0, 0)
+
+    def to_compact_bytes(self) -> bytes:
+        return self.inner.to_compact_bytes()
+
+    def const_coeff_u64(self) -> int:
+        """Constant coefficient through `gpu_matrix_store_const_coeff_batch` + CRT (gpu.rs:1103-1120)."""
+        poly = self.inner.ensure_coeff()
+        residues = [int(v) for v in poly.store_const_coeff_words().reshape(-1)]
+        moduli = poly.params.moduli()[: poly.level + 1]
+        Q = 1
+        for q in moduli:
+            Q *= q
+        acc = 0
+        for r, q in zip(residues, moduli):
+            Qi = Q // q
+            acc += Qi * pow(Qi, -1, q) * r
+        value = acc % Q
+        if value >> 64:
+            raise OverflowError(f"constant coefficient does not fit in u64: {value}")
+        return value
+
+    def extract_bits_with_threshold(self) -> list[bool]:
+        """coefficient in [q/4, 3q/4) -> True (gpu.rs:1070-1081; quarter = (q/2) >> 1)."""
+        quarter = (self.inner.params.modulus() // 2) >> 1
+        return [quarter <= c < 3 * quarter for c in self.coeffs()]
+
+    def to_bool_vec(self) -> list[bool]:
+        out = []
+        for c in self.coeffs():
+            if c not in (0, 1):
+                raise ValueError(f"Coefficient is not 0 or 1: {c}")
+            out.append(c == 1)
+        return out
+
     # ---- arithmetic -------------------------------------------------------------------
     def _pair(self, other):
         assert self.inner.params == other.inner.params
-        a, b = self.inner, other.inner
-        if a.is_ntt != b.is_ntt:
-            a, b = a.ensure_eval(), b.ensure_eval()
-        return a, b
+        # both operands go to EVAL, as in the reference (gpu.rs:1123-1143)
+        return self.inner.ensure_eval(), other.inner.ensure_eval()
 
     def __add__(self, other):
         a, b = self._pair(other)

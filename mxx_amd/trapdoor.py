@@ -24,6 +24,22 @@ def preimage_smoothing_parameter(base: int, sigma: float, d: int, n: int, k: int
     return SPECTRAL_CONSTANT * (base + 1.0) * sigma * sigma * (math.sqrt(d * n * k) + math.sqrt(2 * n) + 4.7)
 
 
+def p1_covariance_parameters(params, d: int, dgg_stddev: float):
+    """(c, s, dgg_stddev) of the p1 covariance cache (trapdoor/gpu.rs:132-143)."""
+    base = 1 << params.base_bits()
+    n, k = params.ring_dimension(), params.modulus_digits()
+    return preimage_c(base, dgg_stddev), preimage_smoothing_parameter(base, dgg_stddev, d, n, k), dgg_stddev
+
+
+def compute_preimage_norm(ring_dim_sqrt: float, m_g: int, base: float, b_nrow=None, sigma=None) -> float:
+    """The preimage coefficient bound the reference's tests check against (src/simulator/eval_error/evaluators.rs:679-700);
+    restated in float64 (the reference uses BigDecimal; the quantities are a few thousand at most)."""
+    sigma = 4.578 if sigma is None else sigma
+    b_nrow = 1 if b_nrow is None else b_nrow
+    term = math.sqrt(b_nrow) * ring_dim_sqrt * math.sqrt(m_g) + math.sqrt(2.0) * ring_dim_sqrt + 4.7
+    return 1.8 * 6.5 * sigma * ((base + 1.0) * sigma) * term
+
+
 def _coeff_cached(m: GpuDCRTPolyMatrix) -> GpuDCRTPolyMatrix:
     return m.clone().into_coeff_domain()
 
@@ -101,6 +117,14 @@ class GpuDCRTPolyTrapdoorSampler:
         self.sigma = float(sigma)
         self.base = 1 << params.base_bits()
         self.c = preimage_c(self.base, self.sigma)
+
+    @staticmethod
+    def trapdoor_to_bytes(trapdoor: "GpuDCRTTrapdoor") -> bytes:
+        return trapdoor.to_compact_bytes()
+
+    @staticmethod
+    def trapdoor_from_bytes(params, data: bytes):
+        return GpuDCRTTrapdoor.from_compact_bytes(params, data)
 
     def trapdoor(self, params, size: int):
         """A = [A_bar | I | G - (A_bar R + E)] (gpu.rs:202-215)."""

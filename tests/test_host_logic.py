@@ -31,8 +31,21 @@ def test_hash_seed_is_deterministic_and_domain_separated():
     s2 = mx.hash_seed_for_matrix(k, b"tag")
     s3 = mx.hash_seed_for_matrix(k, b"tag2")
     assert s1.to_bytes() == s2.to_bytes() != s3.to_bytes()
-    h = hashlib.sha3_256(b"GpuDCRTPolyHashSampler/v2" + k + b"tag" + (0).to_bytes(4, "little")).digest()
-    assert s1.to_bytes() == h
+    msg = b"GpuDCRTPolyHashSampler/v2" + k + b"tag" + (0).to_bytes(4, "little")
+    from mxx_amd.sampler import keccak256
+
+    assert s1.to_bytes() == keccak256(msg)  # the default H is Keccak-256, as in the reference's tests (sampler/gpu.rs:267)
+    assert mx.hash_seed_for_matrix(k, b"tag", "sha3_256").to_bytes() == hashlib.sha3_256(msg).digest()
+
+
+def test_keccak256_known_answers():
+    from mxx_amd.sampler import keccak256
+
+    assert keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    # two absorbed blocks (rate = 136 bytes) and the block-boundary paddings
+    assert keccak256(b"a" * 135).hex() == "34367dc248bbd832f4e3e69dfaac2f92638bd0bbd18f2912ba4ef454919cf446"
+    assert len({keccak256(b"a" * n) for n in (135, 136, 137, 272)}) == 4
 
 
 def test_seed_word_layout():
