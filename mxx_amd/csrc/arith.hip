@@ -103,7 +103,7 @@ __global__ void equal_kernel(const W *__restrict__ a, const W *__restrict__ b, s
 }
 
 // ---- matrix product ---------------------------------------------------------------------
-template <typename W, int TR, int TC, int SV>
+template <typename W, int TR, int TC, int SV, bool PF = false>
 __global__ void __launch_bounds__(256)
     matmul_kernel(W *__restrict__ C, const W *__restrict__ A, const W *__restrict__ B,
                   const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L,
@@ -143,21 +143,28 @@ __global__ void __launch_bounds__(256)
                 for (int s = 0; s < SV; ++s) acc[r][c][s] = 0;
         const uint32_t lazy = lc.lazy_terms;
         uint32_t pending = 0;
-        for (uint32_t k = 0; k < inner; ++k) {
-            W av[TR][SV], bv[TC][SV];
+        // PF: two operand sets, the loads of term k+1 are issued before term k is multiplied.  The lazy-reduction
+        // branch between two iterations keeps the compiler from hoisting them, and a grid with few workgroups - one
+        // rank's column block of a sharded product - then has loads in flight only half of the time
+        // ((1 x 30)(30 x 15), L = 15: 129 -> 87 us).  Large grids hide that with occupancy and lose 3-6 % to the extra
+        // registers, so the host picks PF for small grids only.
+        W av[PF ? 2 : 1][TR][SV], bv[PF ? 2 : 1][TC][SV];
+        auto load = [&](int set, uint32_t k) {
 #pragma unroll
             for (int r = 0; r < TR; ++r)
-                *reinterpret_cast<VT *>(av[r]) = *reinterpret_cast<const VT *>(A + a_off[r] + k * strideA);
+                *reinterpret_cast<VT *>(av[set][r]) = *reinterpret_cast<const VT *>(A + a_off[r] + k * strideA);
 #pragma unroll
             for (int c = 0; c < TC; ++c)
-                *reinterpret_cast<VT *>(bv[c]) = *reinterpret_cast<const VT *>(B + b_off[c] + k * strideBk);
+                *reinterpret_cast<VT *>(bv[set][c]) = *reinterpret_cast<const VT *>(B + b_off[c] + k * strideBk);
+        };
+        auto mac = [&](int set) {
 #pragma unroll
             for (int r = 0; r < TR; ++r)
 #pragma unroll
                 for (int c = 0; c < TC; ++c)
 #pragma unroll
                     for (int s = 0; s < SV; ++s)
-                        acc[r][c][s] += static_cast<uint64_t>(av[r][s]) * static_cast<uint64_t>(bv[c][s]);
+                        acc[r][c][s] += static_cast<uint64_t>(av[set][r][s]) * static_cast<uint64_t>(bv[set][c][s]);
             if (++pending == lazy) {
                 pending = 0;
 #pragma unroll
@@ -166,6 +173,21 @@ __global__ void __launch_bounds__(256)
                     for (int c = 0; c < TC; ++c)
 #pragma unroll
                         for (int s = 0; s < SV; ++s) acc[r][c][s] = reduce_u64_sum(acc[r][c][s], q, lc.mu64);
+            }
+        };
+        if constexpr (PF) {
+            load(0, 0);
+            for (uint32_t k = 0; k < inner; k += 2) {  // the prefetch past the end re-reads the last term and is dropped
+                load(1, min(k + 1, inner - 1));
+                mac(0);
+                if (k + 1 >= inner) break;
+                load(0, min(k + 2, inner - 1));
+                mac(1);
+            }
+        } else {
+            for (uint32_t k = 0; k < inner; ++k) {
+                load(0, k);
+                mac(0);
             }
         }
 #pragma unroll
@@ -406,7 +428,7 @@ static int launch_matmul_lds_u32(GpuMatrix *out, const GpuMatrix *lhs, const Gpu
     return 0;
 }
 
-template <typename W, int TR, int TC, int SV>
+template <typename W, int TR, int TC, int SV, bool PF = false>
 static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
     GpuContext *ctx = out->ctx;
     const uint32_t rows = static_cast<uint32_t>(lhs->rows), inner = static_cast<uint32_t>(lhs->cols),
@@ -417,7 +439,7 @@ static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatr
     const uint32_t gx = (N / SV + threads - 1) / threads;
     if (static_cast<uint64_t>(row_tiles) * col_tiles > 65535) return set_error("gpu_matrix_mul: matrix too large");
     dim3 grid(gx, row_tiles * col_tiles, L);
-    hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV>), grid, dim3(threads), 0, ctx->stream,
+    hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF>), grid, dim3(threads), 0, ctx->stream,
                        static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
                        static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
     HIP_TRY(hipGetLastError());
@@ -469,10 +491,13 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
             const int rc = launch_matmul_dma_u32(out, lhs, rhs);
             if (rc >= 0) return rc;
         }
-        // few rows: the register-tiled kernel streams B once, but with 4 slots per lane a product with few columns
-        // leaves most CUs idle ((1 x 256)(256 x 8): 64 workgroups, 0.90 ms against 0.24 for the 64-slot LDS tile)
-        const uint64_t reg_lanes = static_cast<uint64_t>(rows >= 4 ? N : N / 4) * ((rows + 7) / 8) * ((cols + 7) / 8) * matrix_limbs(out);
-        const bool thin = cols >= 8 && ((rows == 1 && reg_lanes <= 1024ull * 2 * 64) || (rows <= 3 && reg_lanes <= 32768 && inner >= 64));
+        // 1..3 rows: the register tile (4 slots per lane) streams B once and wins wherever its grid reaches the chip; a
+        // small ring with a long inner dimension is a serial chain of `inner` load latencies per wave, and the 64-slot
+        // LDS tile (four times the workgroups, k in chunks of 4) is faster while it fits one resident round of
+        // 512 workgroups (tools/sweep_rowvec.py: n = 4096, L = 8, (1 x 256)(256 x 16): 130 against 175 us)
+        const uint64_t lds_blocks = static_cast<uint64_t>(matrix_limbs(out)) * (N / 64) * ((cols + 15) / 16);
+        const bool thin = rows <= 3 && cols >= 8 &&
+                          lds_blocks <= 512 && (inner >= 128 || (rows >= 2 && inner >= 64));
         const bool want_lds = force ? (force == 'l' || force == 'd' || force == 'w') : ((rows >= 9 && cols >= 8 && !narrow) || thin);
         if (lds_ok && want_lds) return launch_matmul_lds_u32(out, lhs, rhs);
     }
@@ -481,9 +506,13 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
         // ((8 x 1024)(1024 x 64): 7.7 ms against 8.4 for the 16 x 16 LDS tile, which leaves half its rows idle)
         if (rows > 4 && rows <= 8) return launch_matmul_cfg<uint32_t, 8, 8, 1>(out, lhs, rhs);
         if (rows >= 4) return launch_matmul_cfg<uint32_t, 4, 8, 1>(out, lhs, rhs);
-        if (rows >= 2) return launch_matmul_cfg<uint32_t, 2, 8, 4>(out, lhs, rhs);
-        if (cols >= 8) return launch_matmul_cfg<uint32_t, 1, 8, 4>(out, lhs, rhs);
-        return launch_matmul_cfg<uint32_t, 1, 4, 4>(out, lhs, rhs);
+        // 1..3 rows: below ~8 waves per SIMD of tiled work the loads of the next term are issued ahead (PF above)
+        const uint32_t tc = (rows >= 2 || cols >= 8) ? 8 : 4;
+        const uint64_t tile_waves = static_cast<uint64_t>((N / 4 + 63) / 64) * ((rows + 1) / 2) * ((cols + tc - 1) / tc) * matrix_limbs(out);
+        const bool ahead = tile_waves <= (rows >= 2 ? 1024u : 8192u);  // the 2-row tile drops to 2 waves per SIMD with the second operand set
+        if (rows >= 2) return ahead ? launch_matmul_cfg<uint32_t, 2, 8, 4, true>(out, lhs, rhs) : launch_matmul_cfg<uint32_t, 2, 8, 4>(out, lhs, rhs);
+        if (cols >= 8) return ahead ? launch_matmul_cfg<uint32_t, 1, 8, 4, true>(out, lhs, rhs) : launch_matmul_cfg<uint32_t, 1, 8, 4>(out, lhs, rhs);
+        return ahead ? launch_matmul_cfg<uint32_t, 1, 4, 4, true>(out, lhs, rhs) : launch_matmul_cfg<uint32_t, 1, 4, 4>(out, lhs, rhs);
     }
     return launch_matmul_cfg<uint32_t, 1, 4, 1>(out, lhs, rhs);
 }
