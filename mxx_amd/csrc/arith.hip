@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256)
     if (i >= N) return;
     const LimbConst lc = limbs[limb];
     const W q = static_cast<W>(lc.q);
-    typedef typename std::conditional<SV == 4, uint4, typename std::conditional<SV == 2, ulonglong2, W>::type>::type VT;
+    typedef typename std::conditional<sizeof(W) * SV == 16, uint4, typename std::conditional<sizeof(W) * SV == 8, uint2, W>::type>::type VT;
     static_assert(sizeof(VT) == sizeof(W) * SV, "vector width");
 
     const size_t strideA = static_cast<size_t>(L) * N;  // words between consecutive polys
@@ -502,11 +502,29 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
         if (lds_ok && want_lds) return launch_matmul_lds_u32(out, lhs, rhs);
     }
     if (N >= 4) {
+        switch (ctx->env.matmul_tile) {  // tuning override (tools/sweep_tiles.py)
+#define MXX_TILE(R, C, S)                                                                   \
+    case (R * 100 + C * 10 + S) * 2: return launch_matmul_cfg<uint32_t, R, C, S>(out, lhs, rhs); \
+    case (R * 100 + C * 10 + S) * 2 + 1: return launch_matmul_cfg<uint32_t, R, C, S, true>(out, lhs, rhs);
+            MXX_TILE(1, 8, 4) MXX_TILE(1, 4, 4) MXX_TILE(2, 8, 4) MXX_TILE(2, 4, 4) MXX_TILE(3, 4, 4) MXX_TILE(4, 4, 4)
+            MXX_TILE(3, 8, 2) MXX_TILE(4, 8, 1) MXX_TILE(8, 8, 1) MXX_TILE(4, 8, 2)
+#undef MXX_TILE
+            default: break;
+        }
         // 5..8 rows: one 8-row register tile, so that B - the large operand of S * G^-1(B) - is streamed exactly once
         // ((8 x 1024)(1024 x 64): 7.7 ms against 8.4 for the 16 x 16 LDS tile, which leaves half its rows idle)
         if (rows > 4 && rows <= 8) return launch_matmul_cfg<uint32_t, 8, 8, 1>(out, lhs, rhs);
-        if (rows >= 4) return launch_matmul_cfg<uint32_t, 4, 8, 1>(out, lhs, rhs);
-        // 1..3 rows: below ~8 waves per SIMD of tiled work the loads of the next term are issued ahead (PF above)
+        // "ahead" = the loads-ahead form (PF above) for grids too small to hide a load round trip behind other waves
+        if (rows >= 4) {
+            const uint64_t waves4 = static_cast<uint64_t>((N + 63) / 64) * ((cols + 7) / 8) * matrix_limbs(out);
+            return waves4 <= 8192 ? launch_matmul_cfg<uint32_t, 4, 8, 1, true>(out, lhs, rhs) : launch_matmul_cfg<uint32_t, 4, 8, 1>(out, lhs, rhs);
+        }
+        // 3 rows: one 3 x 4 tile of 16-byte loads (two 2-row tiles read B twice: (3 x 30)(30 x 120), L = 15, 919 -> 752 us;
+        // tools/sweep_tiles.py)
+        if (rows == 3) {
+            const uint64_t waves3 = static_cast<uint64_t>((N / 4 + 63) / 64) * ((cols + 3) / 4) * matrix_limbs(out);
+            return waves3 <= 4096 ? launch_matmul_cfg<uint32_t, 3, 4, 4, true>(out, lhs, rhs) : launch_matmul_cfg<uint32_t, 3, 4, 4>(out, lhs, rhs);
+        }
         const uint32_t tc = (rows >= 2 || cols >= 8) ? 8 : 4;
         const uint64_t tile_waves = static_cast<uint64_t>((N / 4 + 63) / 64) * ((rows + 1) / 2) * ((cols + tc - 1) / tc) * matrix_limbs(out);
         const bool ahead = tile_waves <= (rows >= 2 ? 1024u : 8192u);  // the 2-row tile drops to 2 waves per SIMD with the second operand set

@@ -40,6 +40,7 @@ struct EnvSwitches {
     int ntt14 = 0;                // MXX_HIP_NTT14: 0 grouped signed, 1 whole-vector kernel, 2 grouped unsigned
     bool decompose_fused = true;  // MXX_HIP_DECOMPOSE_FUSED=0 disables digits-in-the-NTT-load
     char matmul_path = 0;         // MXX_HIP_MATMUL_PATH: 0 auto, 'r' reg, 'l' lds, 'd' dma, 'w' dma32 (wide tile), 'm' mfma
+    int matmul_tile = 0;          // MXX_HIP_MATMUL_TILE=RCS[p] (tuning: rows, cols, slots per lane of the register tile, p = loads ahead)
     bool gsamp_simple = false;    // MXX_HIP_GSAMP=simple
     bool p1_simple = false;       // MXX_HIP_P1=simple
     int sampler_per_lane = 0;     // MXX_HIP_SAMPLER_PER_LANE (0 = sized for one resident round)

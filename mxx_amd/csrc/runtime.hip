@@ -107,6 +107,9 @@ void EnvSwitches::load() {
     if (const char *e = std::getenv("MXX_HIP_NTT14")) ntt14 = e[0] == 'w' ? 1 : (e[0] == 'u' ? 2 : 0);
     if (const char *e = std::getenv("MXX_HIP_DECOMPOSE_FUSED")) decompose_fused = e[0] != '0';
     if (const char *e = std::getenv("MXX_HIP_MATMUL_PATH")) matmul_path = e[0];
+    if (const char *e = std::getenv("MXX_HIP_MATMUL_TILE")) {
+        if (e[0] && e[1] && e[2]) matmul_tile = ((e[0] - '0') * 100 + (e[1] - '0') * 10 + (e[2] - '0')) * 2 + (e[3] == 'p');
+    }
     if (const char *e = std::getenv("MXX_HIP_GSAMP")) gsamp_simple = e[0] == 's';
     if (const char *e = std::getenv("MXX_HIP_P1")) p1_simple = e[0] == 's';
     if (const char *e = std::getenv("MXX_HIP_SAMPLER_PER_LANE")) {

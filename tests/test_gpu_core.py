@@ -223,6 +223,40 @@ def test_matmul_dma_kernel(gpu, oracle, hip_env, shape, bits, path):
     assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
 
 
+@pytest.mark.parametrize("tile", ["184", "184p", "144p", "284", "284p", "244p", "344", "344p", "444p", "382p", "481", "481p", "881p", "482p"])
+@pytest.mark.parametrize("bits", [24, 31])
+def test_matmul_register_tiles(gpu, oracle, hip_env, tile, bits):
+    """every register-tile shape of matmul_kernel (rows x cols x slots per lane; p = the loads-ahead form with two
+    operand sets) on ragged shapes: odd and even inner dimensions (the loads-ahead loop is unrolled by two), tiles that
+    overhang both edges, worst-case residues, 31-bit primes (accumulators folded inside the loop)."""
+    n = 64
+    moduli = oracle.gen_crt_basis(n, 2, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 8)
+    hip_env.set("MXX_HIP_MATMUL_PATH", "reg")
+    hip_env.set("MXX_HIP_MATMUL_TILE", tile)
+    for (r, k, c) in ((int(tile[0]), 1, int(tile[1])), (int(tile[0]) + 1, 6, 2 * int(tile[1]) + 1), (5, 37, 9), (1, 2, 1)):
+        a = rand_matrix(oracle, 40, r, k, moduli, n)
+        b = np.broadcast_to((np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1), (k, c, len(moduli), n)).copy()
+        b[::2] = rand_matrix(oracle, 41, k, c, moduli, n)[::2]
+        ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+        gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+        assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli)), (tile, r, k, c)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 9), (3, 8, 4), (4, 7, 8), (4, 64, 17), (2, 33, 16), (1, 31, 15)])
+def test_matmul_small_grid_dispatch(gpu, oracle, shape):
+    """the shapes the automatic choice sends to the loads-ahead tiles (3 rows: 3x4x4; 4 rows and 1-2 rows on small grids)"""
+    r, k, c = shape
+    n = 256
+    p = make_params(gpu, oracle, n, 3, 24, 12)
+    moduli = p.moduli()
+    a = rand_matrix(oracle, 42, r, k, moduli, n)
+    b = rand_matrix(oracle, 43, k, c, moduli, n)
+    ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    gb = gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+    assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
+
+
 def test_matmul_lds_lazy_window_31bit(gpu, oracle):
     """LDS kernel with 31-bit primes: the 64-bit accumulators must be folded every chunk."""
     n = 64
