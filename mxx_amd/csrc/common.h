@@ -70,6 +70,7 @@ struct GpuContext {
     void *d_tw2_fwd = nullptr;     // [limb][N] pairs {-w mod 2^W, Shoup(w)} for the lazy forward kernel
     void *d_tw2_inv = nullptr;     // [limb][N] pairs {w, Shoup(w)} for the lazy inverse kernel
     bool lazy_ok = false;          // every modulus < 2^(W-7): lazy LDS kernels are valid
+    bool tight_ok = false;         // 32-bit words, moduli of 26..28 bits: the lazy kernels' TIGHT forms (ntt_lds.h)
     void *d_tw2s_inv = nullptr;    // u32 words, moduli < 2^24: inverse pairs {centred w, floor(w 2^32 / q)} as int32 (ntt14.h)
     bool signed_ok = false;
     uint64_t *d_garner = nullptr;  // [limb][limb] : inverse of q_j mod q_i for j<i

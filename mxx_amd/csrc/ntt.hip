@@ -169,7 +169,7 @@ static int launch_ntt_typed(GpuContext *ctx, W *data, size_t vectors, uint32_t L
     const int force = ctx->env.ntt_path;  // MXX_HIP_NTT_PATH = lds | generic | global (tests exercise every path)
     const bool fits_generic = N * sizeof(W) <= kMaxLdsBytes && logN >= 1;
     if (force == 3) return launch_global<W, INV>(ctx, data, vectors, L);
-    if (force != 2 && ctx->lazy_ok) {  // tuned kernels: whole vector in LDS, or head / tail + sub-vectors beyond it
+    if (force != 2 && (ctx->lazy_ok || ctx->tight_ok)) {  // tuned kernels: whole vector in LDS, or head / tail + sub-vectors beyond it
         int rc;
         if constexpr (sizeof(W) == 4) rc = launch_ntt_lds_u32(ctx, data, vectors, L, INV);
         else rc = launch_ntt_lds_u64(ctx, data, vectors, L, INV);

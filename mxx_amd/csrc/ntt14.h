@@ -44,7 +44,8 @@ __device__ __forceinline__ void wave_sync() {
 
 // forward transform of one vector: `load(e)` supplies coefficient e (natural order), the result
 // (canonical residues, bit-reversed order) goes to g
-template <typename W, typename Load>
+// TIGHT: 26..28-bit moduli (ntt_lds.h): the block passes first bring their inputs (below 16 q) under 8 q
+template <typename W, bool TIGHT, typename Load>
 __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> *__restrict__ tw_all,
                                          const LimbConst &lc, uint32_t limb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,6 +78,7 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             const uint32_t base = pad64(lane);  // pad64(lane + 64 m) = pad64(lane) + 72 m
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[base + 72 * m];
+            ct_prefold<W, 3, TIGHT>(v, q);
             ct_network_lazy<W, 3>(v, tw, B, 5, q, twoq);
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + 72 * m] = v[m];
@@ -87,6 +89,7 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             const uint32_t base = 72 * c + j;  // pad64(64 c + j + 8 m) = 72 c + j + 8 m + 4 (m >> 2)
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m + 4 * (m >> 2)];
+            ct_prefold<W, 3, TIGHT>(v, q);
             ct_network_lazy<W, 3>(v, tw, B * 8u + c, 8, q, twoq);
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + 8 * m + 4 * (m >> 2)] = v[m];
@@ -96,6 +99,7 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             const uint32_t base = pad64(8 * lane);
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[base + m];
+            ct_prefold<W, 3, TIGHT>(v, q);
             ct_network_lazy<W, 3>(v, tw, B * 64u + lane, 11, q, twoq);
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = csub<W>(fold_2q<W>(v[m], q, muw), q);
@@ -114,7 +118,7 @@ struct LoadVector {
     __device__ __forceinline__ W operator()(uint32_t e) const { return g[e]; }
 };
 
-template <typename W>
+template <typename W, bool TIGHT = false>
 __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                uint32_t L) {
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     const size_t vec = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * L + limb;
     const LimbConst lc = limbs[limb];
     W *g = data + vec * N;
-    fwd_body<W>(g, LoadVector<W>{g}, tw_all, lc, limb);
+    fwd_body<W, TIGHT>(g, LoadVector<W>{g}, tw_all, lc, limb);
 }
 
 // Gadget decomposition fused into the transform's load (decompose.hip): output vector
@@ -175,14 +179,15 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     }
     load.q = static_cast<W>(lc.q);
     (void)towers;
-    fwd_body<W>(out + vec * N, load, tw_all, lc, limb);
+    fwd_body<W, false>(out + vec * N, load, tw_all, lc, limb);
 }
 
 // SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)
 // MULW: the transform's load multiplies by a resident EVAL-form ring element first (mulw = {w, Shoup(w)} per
 // limb and slot, `in` = the EVAL operand): data <- INTT(in o w) with one kernel instead of a point-wise pass
 // (a full HBM round trip) followed by the transform - gpupoly_matrix_mul_scalar_intt.
-template <typename W, bool SGN, bool MULW = false>
+// CAP: bound-exponent cap of the unsigned butterflies (kTightCap for 26..28-bit moduli, ntt_lds.h)
+template <typename W, bool SGN, bool MULW = false, int CAP = 31>
 __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
     inv_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                uint32_t L, const W *in = nullptr, const TwPair<W> *__restrict__ mulw = nullptr) {
@@ -224,8 +229,8 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
                 gs_network_signed<3, false>(v, tw, B * 64u + lane, 11, q, lc);
                 gs_fold_signed<3, 0, 2>(v, q, muw);
             } else {
-                gs_network_lazy<W, 3, false>(v, tw, B * 64u + lane, 11, q, lc);
-                gs_fold<W, 3>(v, q, muw);
+                gs_network_lazy<W, 3, false, CAP>(v, tw, B * 64u + lane, 11, q, lc);
+                gs_fold<W, 3, CAP>(v, q, muw);
             }
             const uint32_t base = pad64(8 * lane);
 #pragma unroll
@@ -241,8 +246,8 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
                 gs_network_signed<3, false>(v, tw, B * 8u + c, 8, q, lc);
                 gs_fold_signed<3, 2, 3>(v, q, muw);
             } else {
-                gs_network_lazy<W, 3, false>(v, tw, B * 8u + c, 8, q, lc);
-                gs_fold<W, 3>(v, q, muw);
+                gs_network_lazy<W, 3, false, CAP>(v, tw, B * 8u + c, 8, q, lc);
+                gs_fold<W, 3, CAP>(v, q, muw);
             }
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + 8 * m + 4 * (m >> 2)] = v[m];
@@ -256,8 +261,8 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
                 gs_network_signed<3, false>(v, tw, B, 5, q, lc);
                 gs_fold_signed<3, 3, 1>(v, q, muw);
             } else {
-                gs_network_lazy<W, 3, false>(v, tw, B, 5, q, lc);
-                gs_fold<W, 3>(v, q, muw);
+                gs_network_lazy<W, 3, false, CAP>(v, tw, B, 5, q, lc);
+                gs_fold<W, 3, CAP>(v, q, muw);
             }
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + 72 * m] = v[m];
@@ -269,7 +274,7 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
     }
     // stages 4..0 in registers (N^-1 folded into the last one), coalesced per u
     if constexpr (SGN) gs_network_signed<5, true>(h, tw, 0, 0, q, lc);
-    else gs_network_lazy<W, 5, true>(h, tw, 0, 0, q, lc);
+    else gs_network_lazy<W, 5, true, CAP>(h, tw, 0, 0, q, lc);
 #pragma unroll
     for (int u = 0; u < R0; ++u) g[tid + T * u] = csub<W>(h[u], q);
 }

@@ -75,18 +75,45 @@ __device__ __forceinline__ void ct_network_lazy(W (&v)[1 << C], const TwPair<W> 
     }
 }
 
+// ---- TIGHT mode: moduli of 26..28 bits in 32-bit words (16 q <= 2^32) -----------------------------------------------
+// The reference's end-to-end parameter sets use 28-bit limbs at n = 2^16 (tests/test_gpu_diamond_io.rs:64-70), past the
+// "never correct" bound above.  The forward passes then start by bringing their inputs (below 16 q) under 8 q (passes
+// of up to 4 stages, one subtract + min per element) or under 4 q (5 stages, two), so a pass still ends below 16 q;
+// the inverse passes cap the bound exponents at kTightCap = 4 (see gs_exp_after).  Same bits out.
+constexpr int kTightCap = 4;
+template <typename W, int C, bool TIGHT>
+__device__ __forceinline__ void ct_prefold(W (&v)[1 << C], W q) {
+    if constexpr (TIGHT) {
+#pragma unroll
+        for (int u = 0; u < (1 << C); ++u) {
+            v[u] = csub<W>(v[u], q << 3);
+            if constexpr (C > 4) v[u] = csub<W>(v[u], q << 2);
+        }
+    }
+}
+
 // ---- inverse pass: Gentleman-Sande, input bound 2q, A-path bounds double per stage ----------
-// bound exponent of element u after the stages that used bits 0..j (bound = 2^e * q)
-__host__ __device__ constexpr int gs_exp_after(int u, int j) {
+// bound exponent of element u after the stages that used bits 0..j (bound = 2^e * q).  A stage whose inputs sit at
+// exponent e computes X + M - Y and X + Y below 2^(e+1) q; where that would pass 2^cap q the stage first folds both
+// inputs back to [0, 2q) (exponent 1).  With the default cap no pass of up to 6 stages ever folds; with kTightCap
+// two of the sixteen elements of a 4-stage pass do, before its last stage.
+__host__ __device__ constexpr int gs_exp_after(int u, int j, int cap = 31) {
     int e = 1;
-    for (int i = 0; i <= j; ++i) e = ((u >> i) & 1) ? 1 : e + 1;
+    for (int i = 0; i <= j; ++i) {
+        if ((u >> i) & 1) {
+            e = 1;
+        } else {
+            if (e + 1 > cap) e = 1;
+            e = e + 1;
+        }
+    }
     return e;
 }
 
 // one stage (bit HB of the element index) of the pass; a function template per stage, because the optimiser gives up
 // unrolling the stage loop of the 32-element passes for some instantiations (64-bit words; 2^13 and 2^15 points) -
 // the element array then lives in scratch memory and the inverse transform runs 2-5x slower than the forward one
-template <typename W, int C, bool LAST, int K>
+template <typename W, int C, bool LAST, int K, int CAP>
 __device__ __forceinline__ void gs_stage_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p, W q,
                                               const LimbConst &lc) {
     constexpr int hb = C - K - 1;  // bit used by this stage
@@ -95,9 +122,16 @@ __device__ __forceinline__ void gs_stage_lazy(W (&v)[1 << C], const TwPair<W> *_
 #pragma unroll
     for (int u = 0; u < (1 << C); ++u) {
         if (u & half) continue;
-        const int e_in = hb == 0 ? 1 : gs_exp_after(u, hb - 1);  // same for u and u+half
+        const int e_prev = hb == 0 ? 1 : gs_exp_after(u, hb - 1, CAP);  // same for u and u+half
+        const bool pre = e_prev + 1 > CAP;
+        const int e_in = pre ? 1 : e_prev;
         const W M = q << e_in;                                  // bound of Y
-        const W X = v[u], Y = v[u + half];
+        W X = v[u], Y = v[u + half];
+        if (pre) {
+            const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
+            X = fold_2q<W>(X, q, muw);
+            Y = fold_2q<W>(Y, q, muw);
+        }
         const W D = X + M - Y;
         if (LAST && K == 0) {
             // last stage of the whole transform: fold N^-1 into both outputs
@@ -112,27 +146,27 @@ __device__ __forceinline__ void gs_stage_lazy(W (&v)[1 << C], const TwPair<W> *_
     }
 }
 
-template <typename W, int C, bool LAST, int K>
+template <typename W, int C, bool LAST, int K, int CAP>
 struct GsStages {
     static __device__ __forceinline__ void run(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p, W q,
                                                const LimbConst &lc) {
-        gs_stage_lazy<W, C, LAST, K>(v, tw, bi, s_p, q, lc);
-        if constexpr (K > 0) GsStages<W, C, LAST, K - 1>::run(v, tw, bi, s_p, q, lc);
+        gs_stage_lazy<W, C, LAST, K, CAP>(v, tw, bi, s_p, q, lc);
+        if constexpr (K > 0) GsStages<W, C, LAST, K - 1, CAP>::run(v, tw, bi, s_p, q, lc);
     }
 };
 
-template <typename W, int C, bool LAST>
+template <typename W, int C, bool LAST, int CAP = 31>
 __device__ __forceinline__ void gs_network_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p,
                                                 W q, const LimbConst &lc) {
-    GsStages<W, C, LAST, C - 1>::run(v, tw, bi, s_p, q, lc);  // stages K = C-1 .. 0
+    GsStages<W, C, LAST, C - 1, CAP>::run(v, tw, bi, s_p, q, lc);  // stages K = C-1 .. 0
 }
 
 // bring every element of a finished inverse pass back to [0, 2q)
-template <typename W, int C>
+template <typename W, int C, int CAP = 31>
 __device__ __forceinline__ void gs_fold(W (&v)[1 << C], W q, W muw) {
 #pragma unroll
     for (int u = 0; u < (1 << C); ++u) {
-        const int e = gs_exp_after(u, C - 1);
+        const int e = gs_exp_after(u, C - 1, CAP);
         if (e == 2) v[u] = csub<W>(v[u], q + q);
         else if (e > 2) v[u] = fold_2q<W>(v[u], q, muw);
     }
@@ -220,7 +254,7 @@ __device__ __forceinline__ void lds_set_addr(uint32_t tid, int g, uint32_t &bi, 
 // PRE > 0: the vector has 2^(LOGN + PRE) points and its first PRE stages were done by ntt_fwd_head_kernel; what is
 // left are 2^PRE independent 2^LOGN-point sub-transforms (one workgroup each) whose twiddles sit at stage PRE + s,
 // block (sub << s) + b of the full ring's table.
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0>
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                         uint32_t L) {
@@ -242,6 +276,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         W v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = g[tid + T * u];
+        if constexpr (PRE > 0) ct_prefold<W, LOGR, TIGHT>(v, q);  // the head kernel leaves (1 + 2 PRE) q
         ct_network_lazy<W, LOGR>(v, tw, sub, PRE, q, twoq);
         const uint32_t pb = lds_pad_c(tid);
 #pragma unroll
@@ -255,6 +290,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         W v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
+        ct_prefold<W, LOGR, TIGHT>(v, q);
         ct_network_lazy<W, LOGR>(v, tw, (sub << LOGR) + bi, PRE + LOGR, q, twoq);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = v[u];
@@ -269,6 +305,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
             W v[E];
 #pragma unroll
             for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
+            ct_prefold<W, CLAST, TIGHT>(v, q);
             ct_network_lazy<W, CLAST>(v, tw, (sub << (2 * LOGR)) + tid * G + gi, PRE + 2 * LOGR, q, twoq);
             // canonical form: values < (1 + 2 logN) q
 #pragma unroll
@@ -287,7 +324,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
 }
 
 // PRE > 0: the last PRE stages (and the N^-1 scaling) are left to ntt_inv_tail_kernel; outputs stay below 2q
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0>
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_inv_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                         uint32_t L) {
@@ -295,6 +332,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     constexpr uint32_t N = Cfg::N, T = Cfg::T;
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
     static_assert(P == 3, "three passes");
+    constexpr int CAP = TIGHT ? kTightCap : 31;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
     const uint32_t tid = threadIdx.x;
@@ -324,8 +362,8 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
             W v[E];
 #pragma unroll
             for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
-            gs_network_lazy<W, CLAST, false>(v, tw, (sub << (2 * LOGR)) + tid * G + gi, PRE + 2 * LOGR, q, lc);
-            gs_fold<W, CLAST>(v, q, muw);
+            gs_network_lazy<W, CLAST, false, CAP>(v, tw, (sub << (2 * LOGR)) + tid * G + gi, PRE + 2 * LOGR, q, lc);
+            gs_fold<W, CLAST, CAP>(v, q, muw);
 #pragma unroll
             for (int u = 0; u < E; ++u) x[pb0 + gi * E + u] = v[u];
         }
@@ -338,8 +376,8 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         W v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
-        gs_network_lazy<W, LOGR, false>(v, tw, (sub << LOGR) + bi, PRE + LOGR, q, lc);
-        gs_fold<W, LOGR>(v, q, muw);
+        gs_network_lazy<W, LOGR, false, CAP>(v, tw, (sub << LOGR) + bi, PRE + LOGR, q, lc);
+        gs_fold<W, LOGR, CAP>(v, q, muw);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = v[u];
     }
@@ -350,14 +388,14 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(T * u)];
         if constexpr (PRE == 0) {
-            gs_network_lazy<W, LOGR, true>(v, tw, 0, 0, q, lc);
+            gs_network_lazy<W, LOGR, true, CAP>(v, tw, 0, 0, q, lc);
             // elements that did not go through the N^-1 Shoup product of the last stage carry
             // A-path bounds from the earlier stages of this pass; those that did are < 2q
 #pragma unroll
             for (int u = 0; u < R; ++u) g[tid + T * u] = csub<W>(v[u], q);
         } else {
-            gs_network_lazy<W, LOGR, false>(v, tw, sub, PRE, q, lc);
-            gs_fold<W, LOGR>(v, q, muw);  // below 2q: the input bound of the tail kernel's butterflies
+            gs_network_lazy<W, LOGR, false, CAP>(v, tw, sub, PRE, q, lc);
+            gs_fold<W, LOGR, CAP>(v, q, muw);  // below 2q: the input bound of the tail kernel's butterflies
 #pragma unroll
             for (int u = 0; u < R; ++u) g[tid + T * u] = v[u];
         }
@@ -391,7 +429,7 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = v[u];
 }
 
-template <typename W, int PRE>
+template <typename W, int PRE, bool TIGHT = false>
 __global__ void __launch_bounds__(256)
     ntt_inv_tail_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                         uint32_t L, uint32_t logN) {
@@ -408,7 +446,7 @@ __global__ void __launch_bounds__(256)
     W v[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) v[u] = g[static_cast<size_t>(S) * u];
-    gs_network_lazy<W, PRE, true>(v, tw, 0, 0, q, lc);
+    gs_network_lazy<W, PRE, true, TIGHT ? kTightCap : 31>(v, tw, 0, 0, q, lc);
 #pragma unroll
     for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = csub<W>(v[u], q);
 }

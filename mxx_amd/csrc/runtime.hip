@@ -405,6 +405,7 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
     }
     ctx->crt_bits = crt_bits;
     ctx->lazy_ok = crt_bits + 7 <= (wide ? 64u : 32u);
+    ctx->tight_ok = !wide && !ctx->lazy_ok && crt_bits + 4 <= 32u;
     ctx->signed_ok = !wide && crt_bits <= 24;  // signed lazy inverse butterflies: 2^6 q < 2^30 (ntt_lds.h)
 
     // Garner table: garner_inv[i*L + j] = (q_j)^-1 mod q_i for j < i

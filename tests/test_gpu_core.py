@@ -583,6 +583,69 @@ def test_ntt_large_ring_dimensions(gpu, oracle, logn):
     assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, gy.to_compact_bytes()) == gy
 
 
+@pytest.mark.parametrize("bits", [26, 27, 28])
+@pytest.mark.parametrize("logn", [10, 11, 12, 13, 14, 15, 16, 17])
+def test_ntt_28_bit_moduli_tight_lazy_kernels(gpu, oracle, hip_env, logn, bits):
+    """26..28-bit limbs in 32-bit words (the reference's end-to-end parameter sets: crt_bits = 28 at n = 2^16,
+    tests/test_gpu_diamond_io.rs:64-70): the lazy kernels' tight forms (16 q <= 2^32: forward passes re-centre their
+    inputs, inverse passes cap the bound exponents at 4) against the oracle and the fully reduced kernels, on the
+    largest such primes, with extreme inputs (all q - 1, alternating 0 / q - 1 at several periods, a spike)."""
+    n = 1 << logn
+    moduli = oracle.gen_crt_basis(n, 2, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 14)
+    top = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1)
+    pats = [rand_matrix(oracle, 120 + logn, 1, 1, moduli, n), np.broadcast_to(top, (1, 1, len(moduli), n)).copy()]
+    for period in (2, 32, 1024, n):
+        m = np.broadcast_to(top, (1, 1, len(moduli), n)).copy()
+        m[..., (np.arange(n) // (period // 2)) % 2 == 1] = 0
+        pats.append(m)
+    spike = np.zeros((1, 1, len(moduli), n), dtype=np.uint64)
+    spike[..., n - 1] = top[..., 0]
+    pats.append(spike)
+    x = np.concatenate(pats, axis=1)
+    want = oracle.matrix_ntt(x, moduli)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), want)
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+    e = gpu.GpuDCRTPolyMatrix.from_rns(p, x, True)  # the same patterns as evaluation-domain inputs of the inverse
+    e.intt_all_in_place()
+    assert np.array_equal(e.to_rns(), oracle.matrix_ntt(x, moduli, inverse=True))
+    hip_env.set("MXX_HIP_NTT_PATH", "global" if logn > 15 else "generic")
+    g = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    g.ntt_all_in_place()
+    assert np.array_equal(g.to_rns(), want)
+    hip_env.unset("MXX_HIP_NTT_PATH")
+    if logn == 14:
+        hip_env.set("MXX_HIP_NTT14", "whole")
+        w = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+        w.ntt_all_in_place()
+        assert np.array_equal(w.to_rns(), want)
+        w.intt_all_in_place()
+        assert np.array_equal(w.to_rns(), x)
+
+
+def test_28_bit_ring_whole_path(gpu, oracle):
+    """n = 2^16, 28-bit limbs: product, decompose, Gaussian matrix and compact bytes ride on the tight transforms."""
+    n = 1 << 16
+    moduli = oracle.gen_crt_basis(n, 3, 28)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 14)
+    x = rand_matrix(oracle, 131, 1, 2, moduli, n)
+    y = rand_matrix(oracle, 132, 2, 1, moduli, n)
+    gx = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False).ensure_eval()
+    gy = gpu.GpuDCRTPolyMatrix.from_rns(p, y, False).ensure_eval()
+    prod = gx * gy
+    assert np.array_equal(prod.to_rns(), oracle.matmul(oracle.matrix_ntt(x, moduli), oracle.matrix_ntt(y, moduli), moduli))
+    dec = gy.decompose()
+    assert np.array_equal(dec.to_coeff_rns(), oracle.decompose(y, moduli, 14))
+    assert gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 2) * dec == gy
+    sd = bytes(range(32))
+    g = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 1, 1, oracle.DIST["gauss"], 7.5, gpu.GpuRngSeed.from_bytes(sd))
+    assert np.array_equal(g.to_coeff_rns(), oracle.sample_distribution(1, 1, moduli, n, "gauss", 7.5, sd))
+    assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, prod.to_compact_bytes()) == prod
+
+
 @pytest.mark.parametrize("logn,bits", [(15, 51), (16, 51), (17, 51), (16, 24), (17, 24)])
 def test_ntt_beyond_lds_split_kernels_equal_the_per_stage_path(gpu, oracle, hip_env, logn, bits):
     """Rings whose vectors do not fit LDS (u32 from 2^16 points, u64 from 2^15): the two-kernel transform (outer stages
