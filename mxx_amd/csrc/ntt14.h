@@ -154,7 +154,7 @@ struct LoadDigit {
 // blockIdx.y = t * dpt + d, blockIdx.z = r.  The L * dpt transforms that read one source vector (entry, tower t) then
 // have the same block id modulo 8, i.e. run on one XCD and share its L2 (hardware places consecutive workgroup ids
 // on consecutive XCDs; with limb fastest in x the eight limbs of a source landed on eight different L2s).
-template <typename W, bool REDUCE>
+template <typename W, bool REDUCE, bool TIGHT = false>
 __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
                       const LimbConst *__restrict__ limbs, uint32_t L, uint32_t src_cols, uint32_t towers, uint32_t dpt,
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     }
     load.q = static_cast<W>(lc.q);
     (void)towers;
-    fwd_body<W, false>(out + vec * N, load, tw_all, lc, limb);
+    fwd_body<W, TIGHT>(out + vec * N, load, tw_all, lc, limb);
 }
 
 // SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)

@@ -429,6 +429,49 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = v[u];
 }
 
+// The head kernel with the gadget decomposition in its load (decompose.hip): output vector (orow, col, limb), orow =
+// r k + t dpt + d, starts from digit d of the tower-t coefficient residues of source entry (r, col) instead of from its
+// own contents.  Two-step decomposition at these sizes costs five passes over the k-times larger digit matrix (digits
+// written, head read + write, sub-vectors read + write); this way three.
+// grid = (sets_blocks * L * src_cols, k, source rows)
+template <typename W, int PRE, bool REDUCE>
+__global__ void __launch_bounds__(256)
+    ntt_fwd_head_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
+                               const LimbConst *__restrict__ limbs, uint32_t L, uint32_t logN, uint32_t src_cols, uint32_t dpt,
+                               uint32_t base_bits, uint32_t k) {
+    constexpr int R = 1 << PRE;
+    const uint32_t S = (1u << logN) >> PRE;
+    const uint32_t sets_blocks = S / blockDim.x;
+    const uint32_t sb = blockIdx.x % sets_blocks, rest = blockIdx.x / sets_blocks;
+    const uint32_t limb = rest % L, col = rest / L;
+    const uint32_t td = blockIdx.y, t = td / dpt, d = td - t * dpt;
+    const size_t r = blockIdx.z;
+    const uint32_t j = sb * blockDim.x + threadIdx.x;
+    const LimbConst lc = limbs[limb];
+    const W q = static_cast<W>(lc.q), twoq = q + q;
+    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << logN);
+    const uint32_t src_bits = limbs[t].kbits, shift = d * base_bits;
+    W mask = 0;
+    if (shift < src_bits && shift < 8 * sizeof(W)) {
+        const uint32_t rem = src_bits - shift;
+        const uint32_t db = base_bits < rem ? base_bits : rem;
+        mask = db >= 8 * sizeof(W) ? static_cast<W>(~static_cast<W>(0)) : static_cast<W>((static_cast<W>(1) << db) - 1);
+    }
+    const uint32_t sh = shift < 8 * sizeof(W) ? shift : 0;
+    const W *src = coeff + (((r * src_cols + col) * L + t) << logN) + j;
+    W *g = out + (((((r * k + td) * src_cols + col) * L) + limb) << logN) + j;
+    W v[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const W digit = (src[static_cast<size_t>(S) * u] >> sh) & mask;
+        if constexpr (REDUCE) v[u] = digit >= q ? digit % q : digit;
+        else v[u] = digit;
+    }
+    ct_network_lazy<W, PRE>(v, tw, 0, 0, q, twoq);
+#pragma unroll
+    for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = v[u];
+}
+
 template <typename W, int PRE, bool TIGHT = false>
 __global__ void __launch_bounds__(256)
     ntt_inv_tail_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,

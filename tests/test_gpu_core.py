@@ -364,6 +364,30 @@ def test_decompose_fused_with_ntt_at_2_14(gpu, oracle, hip_env, depth, bits, bas
     assert G * fused == gm.ensure_eval()
 
 
+@pytest.mark.parametrize("logn,depth,bits,base", [(14, 2, 28, 14), (16, 2, 24, 12), (16, 3, 28, 14), (17, 2, 28, 9), (16, 2, 24, 24), (17, 2, 24, 12)])
+def test_decompose_fused_with_ntt_tight_and_split_sizes(gpu, oracle, hip_env, logn, depth, bits, base):
+    """The digit transform fused into the forward NTT's load beyond the 24-bit 2^14 case: 28-bit limbs at 2^14 (tight
+    form of the grouped kernel), and 2^16 / 2^17 points (digits in the load of the head kernel, then the sub-vectors),
+    24- and 28-bit limbs, a base as wide as a limb: against the CPU restatement and the two-step path, small variant,
+    EVAL and COEFF sources, G * G^-1(M) = M."""
+    n = 1 << logn
+    moduli = oracle.gen_crt_basis(n, depth, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, base)
+    M = rand_matrix(oracle, 141 + logn, 1, 2, moduli, n)
+    M[0, 0, :, :3] = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(-1, 1)
+    gm = gpu.GpuDCRTPolyMatrix.from_rns(p, M, False)
+    want = oracle.matrix_ntt(oracle.decompose(M, moduli, base), moduli)
+    fused = gm.decompose()
+    assert fused.is_ntt and np.array_equal(fused.to_rns(), want)
+    assert gm.ensure_eval().decompose() == fused
+    small = gm.small_decompose()
+    assert np.array_equal(small.to_rns(), oracle.matrix_ntt(oracle.decompose(M, moduli, base, small=True), moduli))
+    hip_env.set("MXX_HIP_DECOMPOSE_FUSED", "0")
+    assert gm.decompose() == fused and gm.small_decompose() == small
+    hip_env.unset("MXX_HIP_DECOMPOSE_FUSED")
+    assert gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 1) * fused == gm.ensure_eval()
+
+
 def test_small_decomposed_identity_chunk(gpu, oracle):
     """chunked == full (gpu_dcrt_poly.rs:2225-2334)."""
     n, base = 16, 4
