@@ -668,6 +668,13 @@ def test_28_bit_ring_whole_path(gpu, oracle):
     g = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 1, 1, oracle.DIST["gauss"], 7.5, gpu.GpuRngSeed.from_bytes(sd))
     assert np.array_equal(g.to_coeff_rns(), oracle.sample_distribution(1, 1, moduli, n, "gauss", 7.5, sd))
     assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, prod.to_compact_bytes()) == prod
+    # the reference's trapdoor predicates on this ring (src/sampler/trapdoor/gpu.rs:558-633)
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, 4.578)
+    trapdoor, public_matrix = sampler.trapdoor(p, 1)
+    target = gpu.GpuDCRTPolyUniformSampler().sample_uniform(p, 1, 2, gpu.DistType.FinRingDist())
+    preimage = sampler.preimage(p, trapdoor, public_matrix, target)
+    assert public_matrix * preimage == target
+    assert gx.mul_scalar_intt(gpu.GpuDCRTPolyMatrix.from_rns(p, y[:1], False).ensure_eval()) == (gx.mul_scalar(gpu.GpuDCRTPolyMatrix.from_rns(p, y[:1], False).ensure_eval())).into_coeff_domain()
 
 
 @pytest.mark.parametrize("logn,bits", [(15, 51), (16, 51), (17, 51), (16, 24), (17, 24)])
