@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256)
     }
     ct_network_lazy<W, PRE>(v, tw, 0, 0, q, twoq);
 #pragma unroll
-    for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = v[u];
+    for (int u = 0; u < R; ++u) __builtin_nontemporal_store(v[u], g + static_cast<size_t>(S) * u);  // keeps the source vectors (re-read by L * dpt workgroups) in L2
 }
 
 template <typename W, int PRE, bool TIGHT = false>
