@@ -38,6 +38,37 @@ __device__ __forceinline__ W csub(W x, W m) {  // x in [0, 2m) -> [0, m)
     return min(x, static_cast<W>(x - m));
 }
 
+// Non-temporal global accesses of the data vectors (NT): every vector is read once and written once per kernel, while
+// the twiddle tables are re-read by every workgroup - the hint keeps the stream from displacing them in L2.  Same-box
+// A/B (tools/sweep_ntt.py, 4096 polys x 4 limbs): helps the whole-vector-in-LDS kernels from 2^13 points (2^15 inverse
+// 1.66 -> 1.47 ms, forward 1.28 -> 1.21; 2^13 +3 %; 64-bit words from 2^12: 2^14 inverse 2.13 -> 1.93), costs 6-14 % at
+// 2^12 with 32-bit words and 5-9 % in the head / tail + sub-vector pairs (whose hand-over lives in L2 / the Infinity Cache
+// for small batches) - so it is a per-kernel choice.
+template <typename W, int LOGN, int PRE>
+constexpr bool ntt_nt_data() { return PRE == 0 && (sizeof(W) == 4 ? LOGN >= 13 : LOGN >= 12); }
+template <bool NT, typename W>
+__device__ __forceinline__ W nt_load(const W *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename W>
+__device__ __forceinline__ void nt_store(W v, W *p) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT, typename W>
+__device__ __forceinline__ void nt_load16(W *dst, const W *g) {  // 16 bytes global -> dst (LDS or registers)
+    typedef W wx __attribute__((ext_vector_type(16 / sizeof(W))));
+    if constexpr (NT) *reinterpret_cast<wx *>(dst) = __builtin_nontemporal_load(reinterpret_cast<const wx *>(g));
+    else *reinterpret_cast<wx *>(dst) = *reinterpret_cast<const wx *>(g);
+}
+template <bool NT, typename W>
+__device__ __forceinline__ void nt_store16(W *g, const W *src) {
+    typedef W wx __attribute__((ext_vector_type(16 / sizeof(W))));
+    if constexpr (NT) __builtin_nontemporal_store(*reinterpret_cast<const wx *>(src), reinterpret_cast<wx *>(g));
+    else *reinterpret_cast<wx *>(g) = *reinterpret_cast<const wx *>(src);
+}
+
 // -q as a value the optimiser cannot see through: "x + t * nq" then stays one multiply-add (v_mad_u64_u32, low
 // word) instead of being canonicalised back to a multiply and a subtract - same bits, one VALU instruction less
 // per lazy product (one register).
@@ -261,6 +292,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     typedef NttLdsCfg<W, LOGN, LOGR, false> Cfg;
     constexpr uint32_t N = Cfg::N, T = Cfg::T;
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
+    constexpr bool NT = ntt_nt_data<W, LOGN, PRE>();
     static_assert(P == 3, "three passes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
@@ -275,7 +307,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     {   // pass 0: stages [0, LOGR), elements tid + T*u straight from HBM (coalesced per u)
         W v[R];
 #pragma unroll
-        for (int u = 0; u < R; ++u) v[u] = g[tid + T * u];
+        for (int u = 0; u < R; ++u) v[u] = nt_load<NT, W>(g + tid + T * u);
         if constexpr (PRE > 0) ct_prefold<W, LOGR, TIGHT>(v, q);  // the head kernel leaves (1 + 2 PRE) q
         ct_network_lazy<W, LOGR>(v, tw, sub, PRE, q, twoq);
         const uint32_t pb = lds_pad_c(tid);
@@ -314,12 +346,11 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     }
     __syncthreads();
     // LDS -> HBM, 16 bytes per lane
-    typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
     constexpr int VN = 16 / sizeof(W);
 #pragma unroll
     for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
         const uint32_t i = tid + jj * T;
-        reinterpret_cast<V16 *>(g)[i] = *reinterpret_cast<const V16 *>(&x[lds_pad_c(i * VN)]);
+        nt_store16<NT, W>(g + static_cast<size_t>(i) * VN, &x[lds_pad_c(i * VN)]);
     }
 }
 
@@ -333,6 +364,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
     static_assert(P == 3, "three passes");
     constexpr int CAP = TIGHT ? kTightCap : 31;
+    constexpr bool NT = ntt_nt_data<W, LOGN, PRE>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
     const uint32_t tid = threadIdx.x;
@@ -346,12 +378,11 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     W *g = data + (vec << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
 
     // HBM -> LDS, 16 bytes per lane
-    typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
     constexpr int VN = 16 / sizeof(W);
 #pragma unroll
     for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
         const uint32_t i = tid + jj * T;
-        *reinterpret_cast<V16 *>(&x[lds_pad_c(i * VN)]) = reinterpret_cast<const V16 *>(g)[i];
+        nt_load16<NT, W>(&x[lds_pad_c(i * VN)], g + static_cast<size_t>(i) * VN);
     }
     __syncthreads();
     {   // contiguous pass: stages [2 LOGR, LOGN) in GS order
@@ -392,12 +423,12 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
             // elements that did not go through the N^-1 Shoup product of the last stage carry
             // A-path bounds from the earlier stages of this pass; those that did are < 2q
 #pragma unroll
-            for (int u = 0; u < R; ++u) g[tid + T * u] = csub<W>(v[u], q);
+            for (int u = 0; u < R; ++u) nt_store<NT, W>(csub<W>(v[u], q), g + tid + T * u);
         } else {
             gs_network_lazy<W, LOGR, false, CAP>(v, tw, sub, PRE, q, lc);
             gs_fold<W, LOGR, CAP>(v, q, muw);  // below 2q: the input bound of the tail kernel's butterflies
 #pragma unroll
-            for (int u = 0; u < R; ++u) g[tid + T * u] = v[u];
+            for (int u = 0; u < R; ++u) nt_store<NT, W>(v[u], g + tid + T * u);
         }
     }
 }
