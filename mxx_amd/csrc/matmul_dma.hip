@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(512, 2)
             for (int j = 0; j < 8; ++j) {
                 const uint32_t c = c0 + wc * 8 + j;
                 if (c >= cols) continue;
-                C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane] = reduce(acc[i][j]);
+                __builtin_nontemporal_store(reduce(acc[i][j]), C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane);
             }
         }
     };
@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(1024, 4)
             for (int j = 0; j < 4; ++j) {
                 const uint32_t c = c0 + wq * 8u + half * 4u + j;
                 if (c >= cols) continue;
-                C[(static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot] = reduce(acc[i][j]);
+                // non-temporal: C is written once and must not displace the A / B panels their second reader still needs (-2..4 %)
+                __builtin_nontemporal_store(reduce(acc[i][j]), C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot);
             }
         }
     };
