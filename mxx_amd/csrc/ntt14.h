@@ -45,7 +45,11 @@ __device__ __forceinline__ void wave_sync() {
 // forward transform of one vector: `load(e)` supplies coefficient e (natural order), the result
 // (canonical residues, bit-reversed order) goes to g
 // TIGHT: 26..28-bit moduli (ntt_lds.h): the block passes first bring their inputs (below 16 q) under 8 q
-template <typename W, bool TIGHT, typename Load>
+// NTS: non-temporal stores of the finished blocks.  Right for the digit transforms (a k-times larger output that nothing
+// reads back from cache, source vectors re-read by L * dpt workgroups: decompose 18.5 -> 17.9 ms, same-box A/B); wrong for
+// the plain transform, whose output the next kernel often finds in the Infinity Cache (M1: the fused inverse behind a
+// forward transform with such stores ran 158 -> 185 us).
+template <typename W, bool TIGHT, bool NTS, typename Load>
 __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> *__restrict__ tw_all,
                                          const LimbConst &lc, uint32_t limb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -104,14 +108,13 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             for (int m = 0; m < 8; ++m) v[m] = csub<W>(fold_2q<W>(v[m], q, muw), q);
             W *dst = g + B * BLK + 8 * lane;
 #pragma unroll
-            // non-temporal: the finished block is not read again by this kernel, and the digit transforms' source
-            // vectors (re-read by L * dpt workgroups) stay in L2 - decompose 18.5 -> 17.9 ms, same-box A/B
             for (int m = 0; m < 8; m += VN) {
                 typedef W wx __attribute__((ext_vector_type(VN)));
                 wx t;
 #pragma unroll
                 for (int e = 0; e < VN; ++e) t[e] = v[m + e];
-                __builtin_nontemporal_store(t, reinterpret_cast<wx *>(dst + m));
+                if constexpr (NTS) __builtin_nontemporal_store(t, reinterpret_cast<wx *>(dst + m));
+                else *reinterpret_cast<wx *>(dst + m) = t;
             }
         }
         // the other buffer is used next; this one is rewritten two groups later, behind the
@@ -134,7 +137,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     const size_t vec = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * L + limb;
     const LimbConst lc = limbs[limb];
     W *g = data + vec * N;
-    fwd_body<W, TIGHT>(g, LoadVector<W>{g}, tw_all, lc, limb);
+    fwd_body<W, TIGHT, false>(g, LoadVector<W>{g}, tw_all, lc, limb);
 }
 
 // Gadget decomposition fused into the transform's load (decompose.hip): output vector
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     }
     load.q = static_cast<W>(lc.q);
     (void)towers;
-    fwd_body<W, TIGHT>(out + vec * N, load, tw_all, lc, limb);
+    fwd_body<W, TIGHT, true>(out + vec * N, load, tw_all, lc, limb);
 }
 
 // SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)

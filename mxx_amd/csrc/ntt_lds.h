@@ -38,12 +38,14 @@ __device__ __forceinline__ W csub(W x, W m) {  // x in [0, 2m) -> [0, m)
     return min(x, static_cast<W>(x - m));
 }
 
-// Non-temporal global accesses of the data vectors (NT): every vector is read once and written once per kernel, while
-// the twiddle tables are re-read by every workgroup - the hint keeps the stream from displacing them in L2.  Same-box
-// A/B (tools/sweep_ntt.py, 4096 polys x 4 limbs): helps the whole-vector-in-LDS kernels from 2^13 points (2^15 inverse
-// 1.66 -> 1.47 ms, forward 1.28 -> 1.21; 2^13 +3 %; 64-bit words from 2^12: 2^14 inverse 2.13 -> 1.93), costs 6-14 % at
-// 2^12 with 32-bit words and 5-9 % in the head / tail + sub-vector pairs (whose hand-over lives in L2 / the Infinity Cache
-// for small batches) - so it is a per-kernel choice.
+// Non-temporal accesses of the data vectors (template flag NT of the LDS kernels): a vector is read once and written once
+// per kernel while the twiddle tables are re-read by every workgroup - the hint keeps the stream from displacing them in
+// L2.  Same-box A/B (tools/sweep_ntt.py, 4096 polys x 4 limbs): helps the whole-vector-in-LDS kernels from 2^13 points
+// (2^15 inverse 1.63 -> 1.46 ms, forward 1.26 -> 1.16; 64-bit words from 2^12: 2^14 inverse 2.10 -> 1.86), costs 6-14 % at
+// 2^12 with 32-bit words and 5-9 % in the head / tail + sub-vector pairs, whose hand-over lives in L2 / the Infinity Cache.
+// And it is only right for batches well beyond the Infinity Cache: whatever consumes a transform's output next otherwise
+// finds it there (a 268 MB batch: the inverse behind a forward transform with non-temporal stores ran 123 -> 136 us).
+// So: eligible kernels (ntt_nt_data) x batches of at least 1 GiB (the launcher).
 template <typename W, int LOGN, int PRE>
 constexpr bool ntt_nt_data() { return PRE == 0 && (sizeof(W) == 4 ? LOGN >= 13 : LOGN >= 12); }
 template <bool NT, typename W>
@@ -285,14 +287,13 @@ __device__ __forceinline__ void lds_set_addr(uint32_t tid, int g, uint32_t &bi, 
 // PRE > 0: the vector has 2^(LOGN + PRE) points and its first PRE stages were done by ntt_fwd_head_kernel; what is
 // left are 2^PRE independent 2^LOGN-point sub-transforms (one workgroup each) whose twiddles sit at stage PRE + s,
 // block (sub << s) + b of the full ring's table.
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false>
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false, bool NT = false>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                         uint32_t L) {
     typedef NttLdsCfg<W, LOGN, LOGR, false> Cfg;
     constexpr uint32_t N = Cfg::N, T = Cfg::T;
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
-    constexpr bool NT = ntt_nt_data<W, LOGN, PRE>();
     static_assert(P == 3, "three passes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
 }
 
 // PRE > 0: the last PRE stages (and the N^-1 scaling) are left to ntt_inv_tail_kernel; outputs stay below 2q
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false>
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false, bool NT = false>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_inv_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                         uint32_t L) {
@@ -364,7 +365,6 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
     static_assert(P == 3, "three passes");
     constexpr int CAP = TIGHT ? kTightCap : 31;
-    constexpr bool NT = ntt_nt_data<W, LOGN, PRE>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
     const uint32_t tid = threadIdx.x;

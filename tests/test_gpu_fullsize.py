@@ -77,3 +77,21 @@ def test_m3_preimage_relation_and_norm(gpu, oracle, depth):
     assert np.abs(v).max() < 6.5 * s_par
     width = math.sqrt(s_par * s_par - c * c)
     assert 0.9 * width < v[2:].std() < 1.1 * width
+
+
+@pytest.mark.parametrize("logn,bits,polys", [(13, 24, 8192), (15, 28, 2048), (12, 51, 8192)])
+def test_ntt_batches_beyond_the_infinity_cache(gpu, oracle, logn, bits, polys):
+    """Batches of at least 1 GiB take the non-temporal forms of the whole-vector LDS kernels (ntt_lds_dispatch.inc):
+    round trip on the device, the first and last polynomials against the CPU restatement, both directions."""
+    n = 1 << logn
+    moduli = oracle.gen_crt_basis(n, 4, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 12)
+    assert polys * 4 * n * p.ctx().word_bytes() >= 1 << 30
+    m = gpu.GpuDCRTPolyUniformSampler().sample_uniform(p, polys, 1, gpu.DistType.FinRingDist())  # EVAL form
+    ev = m.clone()
+    m.intt_all_in_place()
+    for r in (0, polys - 1):
+        got = m.slice_rows(r, r + 1).to_rns()
+        assert np.array_equal(got, oracle.matrix_ntt(ev.slice_rows(r, r + 1).to_rns(), moduli, inverse=True))
+    m.ntt_all_in_place()
+    assert m == ev
