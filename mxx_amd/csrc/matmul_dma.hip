@@ -72,7 +72,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 __global__ void __launch_bounds__(512, 2)
     kernel_u32(uint32_t *__restrict__ C, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
                const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L, uint32_t N,
-               uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks, uint32_t xcd_remap) {
+               uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks, uint32_t xcd_remap, uint32_t nt_c) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [STAGES][STAGE_ROWS][64]
     const uint32_t tiles = row_tiles * col_tiles;
     uint32_t id = blockIdx.x, tile, group;
@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(512, 2)
             for (int j = 0; j < 8; ++j) {
                 const uint32_t c = c0 + wc * 8 + j;
                 if (c >= cols) continue;
-                __builtin_nontemporal_store(reduce(acc[i][j]), C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane);
+                uint32_t *dst = C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane;
+                if (nt_c) __builtin_nontemporal_store(reduce(acc[i][j]), dst);  // see kernel_u32 of mmdma32 below
+                else *dst = reduce(acc[i][j]);
             }
         }
     };
@@ -253,7 +255,7 @@ constexpr int LOADS_PER_WAVE = (TROWS + TCOLS) * KC / 8 / 16;  // 2 instructions
 __global__ void __launch_bounds__(1024, 4)
     kernel_u32(uint32_t *__restrict__ C, const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
                const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L, uint32_t N,
-               uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks, uint32_t xcd_remap) {
+               uint32_t row_tiles, uint32_t col_tiles, uint32_t slot_chunks, uint32_t xcd_remap, uint32_t nt_c) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tiles = row_tiles * col_tiles;
     uint32_t id = blockIdx.x, tile, group;
@@ -380,8 +382,12 @@ __global__ void __launch_bounds__(1024, 4)
             for (int j = 0; j < 4; ++j) {
                 const uint32_t c = c0 + wq * 8u + half * 4u + j;
                 if (c >= cols) continue;
-                // non-temporal: C is written once and must not displace the A / B panels their second reader still needs (-2..4 %)
-                __builtin_nontemporal_store(reduce(acc[i][j]), C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot);
+                // non-temporal when C is far larger than the Infinity Cache (nt_c, set by the launcher from 1 GiB): it is
+                // written once and must not displace the A / B panels their second reader still needs (-2..4 %); a small C
+                // stays cacheable for whatever reads it next
+                uint32_t *dst = C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot;
+                if (nt_c) __builtin_nontemporal_store(reduce(acc[i][j]), dst);
+                else *dst = reduce(acc[i][j]);
             }
         }
     };
@@ -413,7 +419,7 @@ int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatri
     hipLaunchKernelGGL(mmdma32::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(1024), mmdma32::LDS_BYTES, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
-                       col_tiles, slot_chunks, remap);
+                       col_tiles, slot_chunks, remap, out->bytes >= (size_t(1) << 30) ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -441,7 +447,7 @@ int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix 
     hipLaunchKernelGGL(mmdma::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(512), mmdma::LDS_BYTES, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
-                       col_tiles, slot_chunks, remap);
+                       col_tiles, slot_chunks, remap, out->bytes >= (size_t(1) << 30) ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return 0;
 }
