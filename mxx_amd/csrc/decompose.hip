@@ -155,11 +155,14 @@ static int decompose_impl(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *o
         coeff = tmp;
     }
     const uint32_t towers = small ? 1u : static_cast<uint32_t>(L);
-    if (requested == GPU_POLY_FORMAT_EVAL && !ctx->wide) {
+    if (requested == GPU_POLY_FORMAT_EVAL) {
         // digits generated inside the forward transform's load: no COEFF digit matrix is written
-        const int frc = launch_ntt_digits_u32(ctx, static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(coeff),
-                                              matrix_polys(out) * L, static_cast<uint32_t>(L), (uint32_t)src->cols, towers,
-                                              dpt, base_bits, k);
+        const int frc = ctx->wide ? launch_ntt_digits_u64(ctx, static_cast<uint64_t *>(out->data), static_cast<const uint64_t *>(coeff),
+                                                          matrix_polys(out) * L, static_cast<uint32_t>(L), (uint32_t)src->cols,
+                                                          towers, dpt, base_bits, k)
+                                  : launch_ntt_digits_u32(ctx, static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(coeff),
+                                                          matrix_polys(out) * L, static_cast<uint32_t>(L), (uint32_t)src->cols,
+                                                          towers, dpt, base_bits, k);
         if (frc >= 0) {
             if (tmp) ctx_free(ctx, tmp);
             if (frc == 0) out->format = GPU_POLY_FORMAT_EVAL;

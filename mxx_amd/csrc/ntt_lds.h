@@ -287,10 +287,10 @@ __device__ __forceinline__ void lds_set_addr(uint32_t tid, int g, uint32_t &bi, 
 // PRE > 0: the vector has 2^(LOGN + PRE) points and its first PRE stages were done by ntt_fwd_head_kernel; what is
 // left are 2^PRE independent 2^LOGN-point sub-transforms (one workgroup each) whose twiddles sit at stage PRE + s,
 // block (sub << s) + b of the full ring's table.
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false, bool NT = false>
-__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
-    ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
-                        uint32_t L) {
+// the transform of one (sub-)vector: `load(e)` supplies element e of it, the result goes to g (NT: non-temporal stores)
+template <typename W, int LOGN, int LOGR, int PRE, bool TIGHT, bool NT, typename Load>
+__device__ __forceinline__ void ntt_fwd_lazy_body(W *__restrict__ g, const Load load, const TwPair<W> *__restrict__ tw,
+                                                  const LimbConst &lc, uint32_t sub) {
     typedef NttLdsCfg<W, LOGN, LOGR, false> Cfg;
     constexpr uint32_t N = Cfg::N, T = Cfg::T;
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
@@ -298,17 +298,11 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *x = reinterpret_cast<W *>(smem);
     const uint32_t tid = threadIdx.x;
-    const size_t vec = blockIdx.x >> PRE;
-    const uint32_t sub = blockIdx.x & ((1u << PRE) - 1u);
-    const uint32_t limb = static_cast<uint32_t>(vec % L);
-    const LimbConst lc = limbs[limb];
     const W q = static_cast<W>(lc.q), twoq = q + q;
-    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << (LOGN + PRE));
-    W *g = data + (vec << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
     {   // pass 0: stages [0, LOGR), elements tid + T*u straight from HBM (coalesced per u)
         W v[R];
 #pragma unroll
-        for (int u = 0; u < R; ++u) v[u] = nt_load<NT, W>(g + tid + T * u);
+        for (int u = 0; u < R; ++u) v[u] = load(tid + T * u);
         if constexpr (PRE > 0) ct_prefold<W, LOGR, TIGHT>(v, q);  // the head kernel leaves (1 + 2 PRE) q
         ct_network_lazy<W, LOGR>(v, tw, sub, PRE, q, twoq);
         const uint32_t pb = lds_pad_c(tid);
@@ -353,6 +347,71 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         const uint32_t i = tid + jj * T;
         nt_store16<NT, W>(g + static_cast<size_t>(i) * VN, &x[lds_pad_c(i * VN)]);
     }
+}
+
+
+template <typename W, bool NT>
+struct LoadData {
+    const W *g;
+    __device__ __forceinline__ W operator()(uint32_t e) const { return nt_load<NT, W>(g + e); }
+};
+
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false, bool NT = false>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
+    ntt_fwd_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
+                        uint32_t L) {
+    const size_t vec = blockIdx.x >> PRE;
+    const uint32_t sub = blockIdx.x & ((1u << PRE) - 1u);
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const LimbConst lc = limbs[limb];
+    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << (LOGN + PRE));
+    W *g = data + (vec << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
+    ntt_fwd_lazy_body<W, LOGN, LOGR, PRE, TIGHT, NT>(g, LoadData<W, NT>{g}, tw, lc, sub);
+}
+
+// digit d (shift, mask) of a coefficient-domain source vector: the gadget decomposition inside a transform's load
+template <typename W, bool REDUCE>
+struct LoadDigitOf {
+    const W *src;
+    uint32_t shift;
+    W mask, q;
+    __device__ __forceinline__ W operator()(uint32_t e) const {
+        const W digit = (src[e] >> shift) & mask;
+        if constexpr (REDUCE) return digit >= q ? digit % q : digit;
+        else return digit;
+    }
+};
+template <typename W, bool REDUCE>
+__device__ __forceinline__ LoadDigitOf<W, REDUCE> load_digit_of(const W *src, const LimbConst *limbs, uint32_t t, uint32_t d,
+                                                                uint32_t base_bits, W q) {
+    const uint32_t src_bits = limbs[t].kbits, shift = d * base_bits;
+    W mask = 0;
+    if (shift < src_bits && shift < 8 * sizeof(W)) {
+        const uint32_t rem = src_bits - shift;
+        const uint32_t db = base_bits < rem ? base_bits : rem;
+        mask = db >= 8 * sizeof(W) ? static_cast<W>(~static_cast<W>(0)) : static_cast<W>((static_cast<W>(1) << db) - 1);
+    }
+    return LoadDigitOf<W, REDUCE>{src, shift < 8 * sizeof(W) ? shift : 0u, mask, q};
+}
+
+// decompose + forward transform for the rings whose vector fits LDS (the 2^14 grouped kernel and the head kernel of the
+// larger rings have their own forms): output vector (orow, col, limb), orow = r k + t dpt + d, is the transform of digit d
+// of the tower-t coefficient residues of source entry (r, col).  One pass over the k-times larger digit matrix (written with
+// non-temporal stores) instead of three.  grid = (L * src_cols, k, source rows)
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, bool TIGHT, bool REDUCE>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
+    ntt_fwd_lazy_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
+                               const LimbConst *__restrict__ limbs, uint32_t L, uint32_t src_cols, uint32_t dpt,
+                               uint32_t base_bits, uint32_t k) {
+    const uint32_t limb = blockIdx.x % L, col = blockIdx.x / L;
+    const uint32_t td = blockIdx.y, t = td / dpt, d = td - t * dpt;
+    const size_t r = blockIdx.z;
+    const LimbConst lc = limbs[limb];
+    const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << LOGN);
+    const W *src = coeff + (((r * src_cols + col) * L + t) << LOGN);
+    W *g = out + (((((r * k + td) * src_cols + col) * L) + limb) << LOGN);
+    ntt_fwd_lazy_body<W, LOGN, LOGR, 0, TIGHT, true>(g, load_digit_of<W, REDUCE>(src, limbs, t, d, base_bits, static_cast<W>(lc.q)), tw,
+                                                     lc, 0u);
 }
 
 // PRE > 0: the last PRE stages (and the N^-1 scaling) are left to ntt_inv_tail_kernel; outputs stay below 2q

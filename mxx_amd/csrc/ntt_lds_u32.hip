@@ -22,8 +22,8 @@ int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff,
                           uint32_t src_cols, uint32_t towers, uint32_t dpt, uint32_t base_bits, size_t k) {
     const EnvSwitches &env = ctx->env;
     const bool tight = !ctx->lazy_ok;
-    if ((ctx->logN != 14 && ctx->logN != 16 && ctx->logN != 17) || !(ctx->lazy_ok || ctx->tight_ok) || env.ntt14 == 1 ||
-        env.ntt_path > 1 || !env.decompose_fused || out_vectors > 0x7fffffffull || k >> 32)
+    if (!(ctx->lazy_ok || ctx->tight_ok) || env.ntt14 == 1 || env.ntt_path > 1 || !env.decompose_fused ||
+        out_vectors > 0x7fffffffull || k >> 32)
         return -1;
     if (k == 0 || src_cols == 0 || out_vectors % (k * src_cols * L) != 0) return -1;
     const size_t src_rows = out_vectors / (k * src_cols * L);
@@ -34,12 +34,7 @@ int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff,
     for (uint32_t l = 0; l < L; ++l) min_q = std::min<uint64_t>(min_q, ctx->moduli[l]);
     const bool reduce = digit_bits >= 63 || ((1ull << digit_bits) - 1) >= min_q;
     (void)towers;
-    if (ctx->logN == 16)
-        return tight ? launch_split_digits<12, 4, 1, 4, true>(ctx, out, coeff, L, src_cols, src_rows, dpt, base_bits, k, reduce)
-                     : launch_split_digits<12, 4, 1, 4, false>(ctx, out, coeff, L, src_cols, src_rows, dpt, base_bits, k, reduce);
-    if (ctx->logN == 17)
-        return tight ? launch_split_digits<12, 4, 1, 5, true>(ctx, out, coeff, L, src_cols, src_rows, dpt, base_bits, k, reduce)
-                     : launch_split_digits<12, 4, 1, 5, false>(ctx, out, coeff, L, src_cols, src_rows, dpt, base_bits, k, reduce);
+    if (ctx->logN != 14) return dispatch_ntt_digits(ctx, out, coeff, L, src_cols, src_rows, dpt, base_bits, k, reduce);
     const dim3 grid(8u * L * ((src_cols + 7u) / 8u), static_cast<unsigned>(k), static_cast<unsigned>(src_rows));
     const dim3 block(ntt14::T);
     const size_t lds = ntt14::lds_bytes(sizeof(W));

@@ -364,12 +364,16 @@ def test_decompose_fused_with_ntt_at_2_14(gpu, oracle, hip_env, depth, bits, bas
     assert G * fused == gm.ensure_eval()
 
 
-@pytest.mark.parametrize("logn,depth,bits,base", [(14, 2, 28, 14), (16, 2, 24, 12), (16, 3, 28, 14), (17, 2, 28, 9), (16, 2, 24, 24), (17, 2, 24, 12)])
+@pytest.mark.parametrize("logn,depth,bits,base", [
+    (14, 2, 28, 14), (16, 2, 24, 12), (16, 3, 28, 14), (17, 2, 28, 9), (16, 2, 24, 24), (17, 2, 24, 12),
+    (10, 3, 24, 12), (11, 2, 28, 14), (12, 2, 24, 7), (12, 2, 24, 24), (13, 2, 28, 14), (15, 2, 24, 12), (15, 2, 28, 9),
+    (10, 3, 51, 17), (11, 2, 51, 51), (12, 2, 51, 17), (13, 2, 51, 20), (14, 2, 51, 17), (15, 2, 51, 17), (16, 2, 51, 25)])
 def test_decompose_fused_with_ntt_tight_and_split_sizes(gpu, oracle, hip_env, logn, depth, bits, base):
     """The digit transform fused into the forward NTT's load beyond the 24-bit 2^14 case: 28-bit limbs at 2^14 (tight
-    form of the grouped kernel), and 2^16 / 2^17 points (digits in the load of the head kernel, then the sub-vectors),
-    24- and 28-bit limbs, a base as wide as a limb: against the CPU restatement and the two-step path, small variant,
-    EVAL and COEFF sources, G * G^-1(M) = M."""
+    form of the grouped kernel); 2^16 / 2^17 points and 64-bit words from 2^15 (digits in the load of the head kernel,
+    then the sub-vectors); every ring whose vector fits LDS (2^10..2^13, 2^15; 64-bit words 2^10..2^14) through
+    ntt_fwd_lazy_digits_kernel; 24-, 28- and 51-bit limbs, a base as wide as a limb: against the CPU restatement and
+    the two-step path, small variant, EVAL and COEFF sources, G * G^-1(M) = M."""
     n = 1 << logn
     moduli = oracle.gen_crt_basis(n, depth, bits)
     p = gpu.GpuDCRTPolyParams(n, moduli, base)
