@@ -185,3 +185,20 @@ def test_column_all_gather_uneven_shards_two_ranks_in_one_process(gpu, tmp_path)
     out = subprocess.run([sys.executable, str(script)], env=dict(os.environ), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "UNEVEN_SHARDS_OK" in out.stdout
+
+
+def test_column_all_gather_two_processes_one_gpu_gloo(gpu):
+    """Two ranks on the one GPU of the box (gloo on device tensors - RCCL refuses two ranks per device): the column
+    gather with real inter-process data - in-place path, padded path, uneven shards (tools/rehearse_world2_gloo.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "tools", "rehearse_world2_gloo.py")],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])
+    assert out.stdout.count("WORLD2_GLOO_GATHER_OK") == 2
