@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per block")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo only rehearses the launcher / rendezvous on a GPU-less box (with --dry-run)")
+                    help="gloo rehearses the launcher / rendezvous on a GPU-less box (with --dry-run) and the whole sharded path with more ranks than GPUs (ranks share devices; not a measurement)")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous + one all-reduce, no GPU work")
     return ap.parse_args(argv)
 
@@ -639,6 +639,10 @@ def main():
     if mx.detected_gpu_device_count() == 0:
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
     device = d.local_rank if d.active else 0
+    if d.active and d.backend == "gloo":
+        # rehearsal of the sharded path with more ranks than GPUs (gloo moves device tensors; RCCL refuses two ranks per
+        # device): ranks share the devices that exist.  Timings of such a run say nothing about scaling.
+        device = d.local_rank % mx.detected_gpu_device_count()
     steps, warmup = args.steps, args.warmup
 
     def run(name, steps_, warmup_, repeats_):
