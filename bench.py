@@ -22,8 +22,10 @@ ranks (`value`, `ms_per_step`); after that R further repetitions of the K steps 
 N>1: `python bench.py --gpus N` spawns its N ranks itself (before any GPU call; the driver's torchrun launch is
 detected through WORLD_SIZE and used as is).  One process per GPU; `--scaling strong` (default) splits the
 SAME problem: B/C column blocks (120 -> 15 per GPU at N=8) and target columns (50 -> 7,7,6,...) by
-mxx_amd.parallel.shard_range, every step ending in one RCCL all-gather of the blocks over xGMI
-(SURVEY.md 8e); `--scaling weak` runs the full shape on every rank with no collective.
+mxx_amd.parallel.shard_range; the blocks stay sharded between steps and one RCCL all-gather over xGMI per timed
+region (inside it) assembles the whole matrix (`--gather lazy`, SURVEY.md 8e: the consumer gathers when it needs it;
+`--gather step` exchanges after every step, overlapped with the next); `--scaling weak` runs the full shape on every
+rank with no collective.
 """
 from __future__ import annotations
 
@@ -52,8 +54,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m3a", "m3b", "m4"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--gather", default="lazy", choices=["lazy", "step"],
-                    help="sharded mat-mul: all-gather the product's column blocks once per timed region (the consumer "
-                         "gathers when it needs the whole matrix) or after every step; the preimage gathers every call")
+                    help="sharded runs: all-gather the column blocks (product, preimage) once per timed region - the consumer "
+                         "gathers when it needs the whole matrix - or after every step, overlapped with the next one")
     ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K steps for median / min")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per block")
@@ -405,9 +407,14 @@ class Preimage(Workload):
             self.c_local = len(sr)
             self.target = uniform_matrix(mx, p, self.dsize, self.c_local, 9, total_cols=self.cols, col_start=sr.start)
             self.gather = ColumnAllGather(p, (k + 2) * self.dsize, self.cols, self.depth - 1, d.torch, d.dist, self.device, slots=2)
+            self.lazy_gather = self.args.gather == "lazy"
+            how = ("the preimage blocks stay on the device that sampled them between calls (the reference's fan-out, "
+                   "src/sampler/trapdoor/gpu.rs:371-397, never moves them device to device) and are all-gathered (RCCL, on the "
+                   "device's stream order) ONCE per timed region, inside it - a rank's block is 98 MB per call at N=8, an "
+                   "exchange per call would be xGMI-bound" if self.lazy_gather else
+                   "one RCCL all-gather of the preimage blocks per call, ordered on the device and overlapped with the next call")
             self.sharding = (f"strong: {self.cols} target columns by shard_range ({self.c_local} on this rank), trapdoor "
-                             "replicated, one RCCL all-gather of the preimage blocks per call, ordered on the device and "
-                             "overlapped with the next call")
+                             f"replicated; {how}")
             self.units = self.cols
         else:
             self.c_local = self.cols
@@ -422,7 +429,8 @@ class Preimage(Workload):
         self.x = None
 
     def step(self, i, mark):
-        slot = self.gather_begin(i)
+        per_call = self.gather is not None and not getattr(self, "lazy_gather", False)
+        slot = self.gather_begin(i) if per_call else 0
         if mark:
             self.mark(i, 0)
         if self.c_local:
@@ -432,7 +440,18 @@ class Preimage(Workload):
         if self.gather is not None:
             if not self.c_local:
                 self.x = self.mx.GpuDCRTPolyMatrix(self.params, self.gather.rows, 0, self.depth - 1, True)
-            self.gather_enqueue(i, slot, self.x)
+            if per_call:
+                self.gather_enqueue(i, slot, self.x)
+            else:
+                self._ungathered = True
+
+    def drain(self):
+        if self.gather is not None and getattr(self, "lazy_gather", False):
+            if getattr(self, "_ungathered", False):  # the region's one exchange step
+                self.full = self.gather.gather(self.x)
+                self._ungathered = False
+            return
+        super().drain()
 
     def check(self):
         if self.c_local:
