@@ -596,7 +596,8 @@ def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
         "warmup": warmup,
         "ms_per_step": res["ms_per_step"],
         "higher_is_better": True,
-        "scaling": args.scaling if d.world > 1 else "weak",
+        # the mode of the N-sweep this line belongs to (the same at N = 1): "strong" where the workload splits one problem
+        "scaling": args.scaling if isinstance(wl, (MatMul, Preimage)) else "weak",
         "vs_baseline": None,
         "dtype": "u32" if wl.word == 4 else "u64",
         "data": "synthetic",
