@@ -130,6 +130,16 @@ class Dist:
             self.torch, self.dist = torch, dist
             self.world = dist.get_world_size()
             self.rank = dist.get_rank()
+            # the first collective of a communicator sets up its channels (tens to hundreds of milliseconds): run one of
+            # each kind used below now, so that none of that can land in a timed region even with --warmup 0
+            dev = self.device()
+            one = torch.ones(1024, dtype=torch.int32, device=dev)
+            out = torch.empty(1024 * self.world, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(out, one)
+            dist.all_reduce(torch.ones(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
+            dist.barrier()
+            if self.backend == "nccl":
+                torch.cuda.synchronize()
 
     @property
     def active(self):
@@ -534,6 +544,10 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
             wl.mark(i, j)
     for i in range(warmup):
         wl.step(i, False)
+    if warmup == 0 and wl.gather is not None:
+        # --warmup 0 on a sharded run: the exchange path (staging buffers, RCCL on the engine's stream) is still exercised
+        # once outside the clock - its first use is set-up, not throughput
+        wl.step(0, False)
     wl.drain()
     d.barrier_sync(mx.gpu_device_sync)
     t0 = time.perf_counter()
