@@ -223,7 +223,7 @@ def test_matmul_dma_kernel(gpu, oracle, hip_env, shape, bits, path):
     assert np.array_equal((ga * gb).to_rns(), oracle.matmul(a, b, moduli))
 
 
-@pytest.mark.parametrize("tile", ["184", "184p", "144p", "284", "284p", "244p", "344", "344p", "444p", "382p", "481", "481p", "881p", "482p"])
+@pytest.mark.parametrize("tile", ["184", "184p", "144", "144p", "284", "284p", "244", "244p", "344", "344p", "444", "444p", "382", "382p", "481", "481p", "881", "881p", "482", "482p"])
 @pytest.mark.parametrize("bits", [24, 31])
 def test_matmul_register_tiles(gpu, oracle, hip_env, tile, bits):
     """every register-tile shape of matmul_kernel (rows x cols x slots per lane; p = the loads-ahead form with two
