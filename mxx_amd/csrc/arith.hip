@@ -103,7 +103,7 @@ __global__ void equal_kernel(const W *__restrict__ a, const W *__restrict__ b, s
 }
 
 // ---- matrix product ---------------------------------------------------------------------
-template <typename W, int TR, int TC, int SV, bool PF = false>
+template <typename W, int TR, int TC, int SV, bool PF = false, bool NTB = false>
 __global__ void __launch_bounds__(256)
     matmul_kernel(W *__restrict__ C, const W *__restrict__ A, const W *__restrict__ B,
                   const LimbConst *__restrict__ limbs, uint32_t rows, uint32_t inner, uint32_t cols, uint32_t L,
@@ -155,10 +155,16 @@ __global__ void __launch_bounds__(256)
                 *reinterpret_cast<VT *>(av[set][r]) = *reinterpret_cast<const VT *>(A + a_off[r] + k * strideA);
 #pragma unroll
             for (int c = 0; c < TC; ++c) {
-                // the register tiles stream B exactly once (one row tile): non-temporal loads keep it from displacing A
-                // (read by every column tile) in L2 / the Infinity Cache - M2A 608-629 -> 588 us
+                // NTB (the host sets it when there is ONE row tile): B is then streamed exactly once, and non-temporal loads
+                // keep it from displacing A (read by every column tile) in L2 / the Infinity Cache - M2A 608-629 -> 588 us.
+                // With several row tiles the other tiles re-read B from cache and the hint costs 25-55 %
+                // ((96 x 64)(64 x 8): 0.48 -> 0.79 ms).  A template flag: a run-time `c ? nt_load : load` is merged into one
+                // plain load.
                 typedef uint32_t u32xs __attribute__((ext_vector_type(SV)));
-                const u32xs t = __builtin_nontemporal_load(reinterpret_cast<const u32xs *>(B + b_off[c] + k * strideBk));
+                const u32xs *src = reinterpret_cast<const u32xs *>(B + b_off[c] + k * strideBk);
+                u32xs t;
+                if constexpr (NTB) t = __builtin_nontemporal_load(src);
+                else t = *src;
 #pragma unroll
                 for (int s_ = 0; s_ < SV; ++s_) bv[set][c][s_] = t[s_];
             }
@@ -445,9 +451,14 @@ static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatr
     const uint32_t gx = (N / SV + threads - 1) / threads;
     if (static_cast<uint64_t>(row_tiles) * col_tiles > 65535) return set_error("gpu_matrix_mul: matrix too large");
     dim3 grid(gx, row_tiles * col_tiles, L);
-    hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF>), grid, dim3(threads), 0, ctx->stream,
-                       static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
-                       static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
+    if (sizeof(W) == 4 && row_tiles == 1)  // B is read by this one row tile only: streamed with non-temporal loads
+        hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, sizeof(W) == 4>), grid, dim3(threads), 0, ctx->stream,
+                           static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
+                           static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
+    else
+        hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, false>), grid, dim3(threads), 0, ctx->stream,
+                           static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
+                           static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
     HIP_TRY(hipGetLastError());
     return 0;
 }
