@@ -45,8 +45,8 @@ __device__ __forceinline__ void wave_sync() {
 // forward transform of one vector: `load(e)` supplies coefficient e (natural order), the result
 // (canonical residues, bit-reversed order) goes to g
 // TIGHT: 26..28-bit moduli (ntt_lds.h): the block passes first bring their inputs (below 16 q) under 8 q
-// NTS: non-temporal stores of the finished blocks.  Right for the digit transforms (a k-times larger output that nothing
-// reads back from cache, source vectors re-read by L * dpt workgroups: decompose 18.5 -> 17.9 ms, same-box A/B); wrong for
+// NTS: non-temporal stores of the finished blocks.  Right for LARGE digit transforms (the host sets it from 1 GiB of
+// output: a k-times larger matrix that nothing reads back from cache, source vectors re-read by L * dpt workgroups: decompose 18.5 -> 17.9 ms, same-box A/B); wrong for
 // the plain transform, whose output the next kernel often finds in the Infinity Cache (M1: the fused inverse behind a
 // forward transform with such stores ran 158 -> 185 us).
 template <typename W, bool TIGHT, bool NTS, typename Load>
@@ -164,7 +164,7 @@ struct LoadDigit {
 // blockIdx.y = t * dpt + d, blockIdx.z = r.  The L * dpt transforms that read one source vector (entry, tower t) then
 // have the same block id modulo 8, i.e. run on one XCD and share its L2 (hardware places consecutive workgroup ids
 // on consecutive XCDs; with limb fastest in x the eight limbs of a source landed on eight different L2s).
-template <typename W, bool REDUCE, bool TIGHT = false>
+template <typename W, bool REDUCE, bool TIGHT = false, bool NTS = false>
 __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
                       const LimbConst *__restrict__ limbs, uint32_t L, uint32_t src_cols, uint32_t towers, uint32_t dpt,
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     }
     load.q = static_cast<W>(lc.q);
     (void)towers;
-    fwd_body<W, TIGHT, true>(out + vec * N, load, tw_all, lc, limb);
+    fwd_body<W, TIGHT, NTS>(out + vec * N, load, tw_all, lc, limb);
 }
 
 // SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)

@@ -397,8 +397,8 @@ __device__ __forceinline__ LoadDigitOf<W, REDUCE> load_digit_of(const W *src, co
 // decompose + forward transform for the rings whose vector fits LDS (the 2^14 grouped kernel and the head kernel of the
 // larger rings have their own forms): output vector (orow, col, limb), orow = r k + t dpt + d, is the transform of digit d
 // of the tower-t coefficient residues of source entry (r, col).  One pass over the k-times larger digit matrix (written with
-// non-temporal stores) instead of three.  grid = (L * src_cols, k, source rows)
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, bool TIGHT, bool REDUCE>
+// non-temporal stores, NTS, when it is at least 1 GiB) instead of three.  grid = (L * src_cols, k, source rows)
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, bool TIGHT, bool REDUCE, bool NTS>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_fwd_lazy_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
                                const LimbConst *__restrict__ limbs, uint32_t L, uint32_t src_cols, uint32_t dpt,
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     const TwPair<W> *tw = tw_all + (static_cast<size_t>(limb) << LOGN);
     const W *src = coeff + (((r * src_cols + col) * L + t) << LOGN);
     W *g = out + (((((r * k + td) * src_cols + col) * L) + limb) << LOGN);
-    ntt_fwd_lazy_body<W, LOGN, LOGR, 0, TIGHT, true>(g, load_digit_of<W, REDUCE>(src, limbs, t, d, base_bits, static_cast<W>(lc.q)), tw,
+    ntt_fwd_lazy_body<W, LOGN, LOGR, 0, TIGHT, NTS>(g, load_digit_of<W, REDUCE>(src, limbs, t, d, base_bits, static_cast<W>(lc.q)), tw,
                                                      lc, 0u);
 }
 
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(256)
 // own contents.  Two-step decomposition at these sizes costs five passes over the k-times larger digit matrix (digits
 // written, head read + write, sub-vectors read + write); this way three.
 // grid = (sets_blocks * L * src_cols, k, source rows)
-template <typename W, int PRE, bool REDUCE>
+template <typename W, int PRE, bool REDUCE, bool NTS>
 __global__ void __launch_bounds__(256)
     ntt_fwd_head_digits_kernel(W *__restrict__ out, const W *__restrict__ coeff, const TwPair<W> *__restrict__ tw_all,
                                const LimbConst *__restrict__ limbs, uint32_t L, uint32_t logN, uint32_t src_cols, uint32_t dpt,
@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(256)
     }
     ct_network_lazy<W, PRE>(v, tw, 0, 0, q, twoq);
 #pragma unroll
-    for (int u = 0; u < R; ++u) __builtin_nontemporal_store(v[u], g + static_cast<size_t>(S) * u);  // keeps the source vectors (re-read by L * dpt workgroups) in L2
+    for (int u = 0; u < R; ++u) nt_store<NTS, W>(v[u], g + static_cast<size_t>(S) * u);  // NTS (large outputs): keeps the source vectors (re-read by L * dpt workgroups) in L2
 }
 
 template <typename W, int PRE, bool TIGHT = false>

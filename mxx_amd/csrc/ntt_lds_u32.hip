@@ -40,9 +40,16 @@ int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff,
     const size_t lds = ntt14::lds_bytes(sizeof(W));
     const TwPair<W> *tw = static_cast<const TwPair<W> *>(ctx->d_tw2_fwd);
     const uint32_t k32 = static_cast<uint32_t>(k);
-#define MXX_DIGITS(RED, TGT)                                                                                              \
-    hipLaunchKernelGGL((ntt14::fwd_digits_kernel<W, RED, TGT>), grid, block, lds, ctx->stream, out, coeff, tw, ctx->d_limbs, L, \
-                       src_cols, towers, dpt, base_bits, k32)
+    const bool nts = out_vectors * sizeof(W) * ntt14::N >= (size_t(1) << 29);  // outputs that fit the Infinity Cache stay cacheable for their consumer ((1 x 64) G^-1(4 x 4): 180 -> 168 us); from 0.5 GB the hint wins (8 x 8: 442 -> 390 us)
+#define MXX_DIGITS(RED, TGT)                                                                                                     \
+    do {                                                                                                                         \
+        if (nts)                                                                                                                 \
+            hipLaunchKernelGGL((ntt14::fwd_digits_kernel<W, RED, TGT, true>), grid, block, lds, ctx->stream, out, coeff, tw,      \
+                               ctx->d_limbs, L, src_cols, towers, dpt, base_bits, k32);                                           \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((ntt14::fwd_digits_kernel<W, RED, TGT, false>), grid, block, lds, ctx->stream, out, coeff, tw,     \
+                               ctx->d_limbs, L, src_cols, towers, dpt, base_bits, k32);                                           \
+    } while (0)
     if (reduce) {
         if (tight) MXX_DIGITS(true, true);
         else MXX_DIGITS(true, false);
