@@ -451,7 +451,10 @@ static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatr
     const uint32_t gx = (N / SV + threads - 1) / threads;
     if (static_cast<uint64_t>(row_tiles) * col_tiles > 65535) return set_error("gpu_matrix_mul: matrix too large");
     dim3 grid(gx, row_tiles * col_tiles, L);
-    if (sizeof(W) == 4 && row_tiles == 1)  // B is read by this one row tile only: streamed with non-temporal loads
+    // B is read by this one row tile only and cannot live in the 256 MB Infinity Cache: streamed with non-temporal loads
+    // (a smaller B is often re-used from cache by the next product - the hint made repeated products on a 134 MB operand
+    // 40 % slower)
+    if (sizeof(W) == 4 && row_tiles == 1 && rhs->bytes > (size_t(1) << 28))
         hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, sizeof(W) == 4>), grid, dim3(threads), 0, ctx->stream,
                            static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
                            static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
@@ -513,7 +516,7 @@ int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
         // LDS tile (four times the workgroups, k in chunks of 4) is faster while it fits one resident round of
         // 512 workgroups (tools/sweep_rowvec.py: n = 4096, L = 8, (1 x 256)(256 x 16): 130 against 175 us)
         const uint64_t lds_blocks = static_cast<uint64_t>(matrix_limbs(out)) * (N / 64) * ((cols + 15) / 16);
-        const bool thin = rows <= 3 && cols >= 8 &&
+        const bool thin = rows <= 2 && cols >= 8 &&  // 3 rows: the 3 x 4 register tile wins on nearly every such shape
                           lds_blocks <= 512 && (inner >= 128 || (rows >= 2 && inner >= 64));
         const bool want_lds = force ? (force == 'l' || force == 'd' || force == 'w') : ((rows >= 9 && cols >= 8 && !narrow) || thin);
         if (lds_ok && want_lds) return launch_matmul_lds_u32(out, lhs, rhs);
