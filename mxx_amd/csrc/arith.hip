@@ -240,8 +240,15 @@ __global__ void __launch_bounds__(256)
                 for (int r = 0; r < TR; ++r)
                     *reinterpret_cast<VT *>(av[u][r]) = *reinterpret_cast<const VT *>(A + a_off[r] + k * strideA);
 #pragma unroll
-                for (int c = 0; c < TC; ++c)
-                    *reinterpret_cast<VT *>(bv[u][c]) = *reinterpret_cast<const VT *>(B + b_off[c] + k * strideBk);
+                for (int c = 0; c < TC; ++c) {
+                    typedef W wxs __attribute__((ext_vector_type(SV)));
+                    const wxs *src = reinterpret_cast<const wxs *>(B + b_off[c] + k * strideBk);
+                    wxs t;
+                    if constexpr (NTB) t = __builtin_nontemporal_load(src);  // see the 32-bit branch
+                    else t = *src;
+#pragma unroll
+                    for (int s_ = 0; s_ < SV; ++s_) bv[u][c][s_] = t[s_];
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < KU; ++u) {
@@ -454,8 +461,8 @@ static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatr
     // B is read by this one row tile only and cannot live in the 256 MB Infinity Cache: streamed with non-temporal loads
     // (a smaller B is often re-used from cache by the next product - the hint made repeated products on a 134 MB operand
     // 40 % slower)
-    if (sizeof(W) == 4 && row_tiles == 1 && rhs->bytes > (size_t(1) << 28))
-        hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, sizeof(W) == 4>), grid, dim3(threads), 0, ctx->stream,
+    if (row_tiles == 1 && rhs->bytes > (size_t(1) << 28))
+        hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, true>), grid, dim3(threads), 0, ctx->stream,
                            static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
                            static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
     else

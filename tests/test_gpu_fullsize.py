@@ -95,3 +95,21 @@ def test_ntt_batches_beyond_the_infinity_cache(gpu, oracle, logn, bits, polys):
         assert np.array_equal(got, oracle.matrix_ntt(ev.slice_rows(r, r + 1).to_rns(), moduli, inverse=True))
     m.ntt_all_in_place()
     assert m == ev
+
+
+def test_u64_row_vector_product_beyond_the_infinity_cache(gpu, oracle):
+    """64-bit words, a B operand larger than the Infinity Cache: the register tile streams it with non-temporal loads
+    (arith.hip).  Distributivity, and every column against the one-column product (a B small enough to take the
+    cacheable form of the kernel)."""
+    n = 16384
+    moduli = oracle.gen_crt_basis(n, 4, 51)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 17)
+    us = gpu.GpuDCRTPolyUniformSampler()
+    a1 = us.sample_uniform(p, 1, 16, gpu.DistType.FinRingDist())
+    a2 = us.sample_uniform(p, 1, 16, gpu.DistType.FinRingDist())
+    b = us.sample_uniform(p, 16, 40, gpu.DistType.FinRingDist())
+    assert 16 * 40 * 4 * n * 8 > 1 << 28
+    c1 = a1 * b
+    assert (a1 + a2) * b == c1 + a2 * b
+    for col in (0, 17, 39):
+        assert a1 * b.slice_columns(col, col + 1) == c1.slice_columns(col, col + 1)
