@@ -26,7 +26,7 @@
  *     an event set (possibly NULL) the caller waits on and destroys;
  *     gpu_matrix_equal and the compact-bytes pair are synchronous.
  *   - device layout is private: words [poly][limb][N], poly = row*cols + col,
- *     uint32_t residues when every modulus is < 2^32, uint64_t otherwise.
+ *     uint32_t residues when every modulus is < 2^31, uint64_t otherwise.
  *   - EVAL format is OpenFHE's: slot k of limb i holds a(psi_i^(2*bitrev(k)+1))
  *     with psi_i the minimum primitive 2N-th root mod q_i (the reference CPU
  *     path's convention), so EVAL bytes are interchangeable with the CPU side.
@@ -45,6 +45,7 @@ typedef struct GpuContext GpuContext;
 typedef struct GpuMatrix GpuMatrix;
 typedef struct GpuEventSet GpuEventSet;
 typedef struct GpuP1CovarianceCache GpuP1CovarianceCache;
+typedef struct GpuComm GpuComm; /* extension: communicator over the device contexts of ONE process */
 
 /* src/poly/dcrt/gpu.rs:45-61, cuda/include/ChaCha.cuh:9-12 — passed BY VALUE */
 typedef struct GpuRngSeed {
@@ -208,6 +209,24 @@ int gpupoly_context_device(const GpuContext *ctx, int *out_device);
 int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes);
 /* the context's compute stream (hipStream_t): lets the host order collectives against engine work on the device */
 int gpupoly_context_stream(const GpuContext *ctx, void **out_stream);
+/* ---- multi-GPU exchange, one process / N device contexts ----------------------------------------
+ * The reference runs ONE process with a context per device (`params_for_device`, src/poly/dcrt/gpu.rs:531-557) and
+ * rayon over them (`preimage_batched_sharded`, src/sampler/trapdoor/gpu.rs:371-397); whatever has to exist on another
+ * device travels through host bytes.  A communicator binds such contexts (the same ring on every one).  Backend
+ * "rccl": ncclCommInitAll over the contexts' devices (librccl is loaded when the first communicator is created),
+ * collectives enqueued on each context's own stream, xGMI between the devices.  Backend "peer": device-to-device
+ * pulls ordered by events - chosen when contexts share a device (RCCL refuses that) or with MXX_HIP_COMM=peer.     */
+int gpupoly_comm_create(GpuContext *const *ctxs, size_t n, GpuComm **out_comm);
+void gpupoly_comm_destroy(GpuComm *comm);
+int gpupoly_comm_size(const GpuComm *comm, int *out_size);
+const char *gpupoly_comm_backend(const GpuComm *comm); /* "rccl" or "peer" */
+/* All-gather of the column blocks of a column-sharded matrix: local_blocks[r] (rows x c_r, in context r, any format,
+ * the same one everywhere) lands in columns [c_0 + .. + c_(r-1), +c_r) of full[s] (rows x sum c_r, in context s) for
+ * every s; full[s] takes the blocks' format tag.  Shards may be uneven or empty.  Enqueued on the contexts' streams
+ * behind whatever produced the blocks; the host does not block; a block may be overwritten or destroyed right after
+ * the call.  One row and equal shards gather straight into full[s]; other shapes go through a padded staging block
+ * of the context's allocator.  Call it from one host thread (after the per-device workers have joined).           */
+int gpupoly_matrix_all_gather_columns(GpuComm *comm, const GpuMatrix *const *local_blocks, GpuMatrix *const *full);
 const char *gpupoly_version(void);
 /* MXX_HIP_* switches are read once, at gpu_context_create; this re-reads them for every live
  * context of the process (tests flip them between calls).                      */

@@ -115,6 +115,11 @@ SIGNATURES = {
     "gpupoly_context_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_context_word_bytes": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_context_stream": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "gpupoly_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(_vp)]),
+    "gpupoly_comm_destroy": (None, [_vp]),
+    "gpupoly_comm_size": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gpupoly_comm_backend": (C.c_char_p, [_vp]),
+    "gpupoly_matrix_all_gather_columns": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "gpupoly_version": (C.c_char_p, []),
     "gpupoly_reload_env": (C.c_int, []),
 }

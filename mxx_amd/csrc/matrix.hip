@@ -152,14 +152,13 @@ int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size
         if (out == src) {
             // overlapping self-copy: go through the kernel only when disjoint is not guaranteed
             // (hipMemcpy2D has undefined overlap semantics); use a temp
-            void *tmp = nullptr;
+            CtxBlock tmp(ctx);  // back to the cache at scope exit, error paths included
             size_t row_bytes = cols * wpp * wb;
-            if (ctx_alloc(ctx, rows * row_bytes, &tmp)) return 1;
-            HIP_TRY(hipMemcpy2DAsync(tmp, row_bytes, s, src->cols * wpp * wb, row_bytes, rows,
+            if (tmp.alloc(rows * row_bytes)) return 1;
+            HIP_TRY(hipMemcpy2DAsync(tmp.ptr, row_bytes, s, src->cols * wpp * wb, row_bytes, rows,
                                      hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, tmp, row_bytes, row_bytes, rows,
+            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, tmp.ptr, row_bytes, row_bytes, rows,
                                      hipMemcpyDeviceToDevice, ctx->stream));
-            ctx_free(ctx, tmp);
             return 0;
         }
         if (rows == 1 || (cols == src->cols && cols == out->cols)) {

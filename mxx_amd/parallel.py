@@ -189,3 +189,64 @@ class ColumnAllGather:
     def gather(self, local, slot: int = 0):
         """local: this rank's rows x len(shard) block.  Returns the full matrix, valid on the engine's stream."""
         return self.finish(self.start(local, slot))
+
+
+class GpuComm:
+    """Communicator over the device contexts of THIS process (`gpupoly_comm_create`): the reference's own multi-GPU
+    model - one process, a context per device (`params_for_device`, src/poly/dcrt/gpu.rs:531-557), rayon over them
+    (src/sampler/trapdoor/gpu.rs:371-397) - with the exchange step on the devices (RCCL over xGMI, or event-ordered
+    peer pulls when contexts share a device) instead of through host bytes.  No torch involved."""
+
+    def __init__(self, params_list):
+        import ctypes as C
+
+        from . import _ffi
+
+        self.params = list(params_list)
+        arr = (C.c_void_p * len(self.params))(*[p.ctx_raw() for p in self.params])
+        raw = C.c_void_p()
+        _ffi.check_status(_ffi.lib().gpupoly_comm_create(arr, len(self.params), C.byref(raw)), "gpupoly_comm_create")
+        self.raw = raw
+
+    def __len__(self):
+        return len(self.params)
+
+    @property
+    def backend(self) -> str:
+        from . import _ffi
+
+        return _ffi.lib().gpupoly_comm_backend(self.raw).decode()
+
+    def all_gather_columns(self, local_blocks, fulls=None):
+        """local_blocks[r]: rows x c_r block living in context r.  Returns the list of full matrices (one per context),
+        valid on each context's stream; `fulls` re-uses caller-owned outputs."""
+        import ctypes as C
+
+        from . import _ffi
+        from .matrix import GpuDCRTPolyMatrix
+
+        n = len(self.params)
+        assert len(local_blocks) == n, "one block per context"
+        total = sum(b.ncol for b in local_blocks)
+        if fulls is None:
+            b0 = local_blocks[0]
+            fulls = [GpuDCRTPolyMatrix(p, b0.nrow, total, b0.level, b0.is_ntt) for p in self.params]
+        la = (C.c_void_p * n)(*[b.raw for b in local_blocks])
+        fa = (C.c_void_p * n)(*[f.raw for f in fulls])
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_all_gather_columns(self.raw, la, fa), "gpupoly_matrix_all_gather_columns")
+        for f in fulls:
+            f.is_ntt = local_blocks[0].is_ntt
+        return fulls
+
+    def close(self):
+        from . import _ffi
+
+        if self.raw:
+            _ffi.lib().gpupoly_comm_destroy(self.raw)
+            self.raw = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,149 @@
+"""GPU: the multi-GPU exchange step through the C ABI (gpupoly_comm_* / gpupoly_matrix_all_gather_columns) -
+one process, a context per device, as the reference runs (`params_for_device`, src/poly/dcrt/gpu.rs:531-557;
+`preimage_batched_sharded`, src/sampler/trapdoor/gpu.rs:371-397).  This box has ONE device: the RCCL backend is
+exercised with a 1-device communicator, the shard logic with several contexts on that device (event-ordered peer
+pulls - RCCL refuses two ranks per device).  Everything is compared with the oracle's concatenation."""
+import numpy as np
+import pytest
+
+from conftest import make_params, rand_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def contexts_on_one_device(gpu, oracle, count, n=1024, depth=3, bits=24):
+    p0 = make_params(gpu, oracle, n, depth, bits, 12)
+    out = [p0]
+    for i in range(1, count):  # same ring, different dnum -> its own context / stream / allocator cache
+        out.append(gpu.GpuDCRTPolyParams(n, p0.moduli(), 12, gpu_ids=p0.gpu_ids(), dnum=100 + i))
+    assert len({p.ctx_raw().value for p in out}) == count
+    return out
+
+
+@pytest.mark.parametrize("rows,shards,eval_format", [(1, [2], True), (3, [4], False), (1, [0], True)])
+def test_all_gather_columns_rccl_one_device(gpu, oracle, rows, shards, eval_format):
+    """ncclCommInitAll over one device, ncclAllGather on the context's stream, straight into the output (1 row) or
+    through the padded staging block (3 rows); COEFF blocks keep their tag on both sides of the ABI."""
+    from mxx_amd.parallel import GpuComm
+
+    (p,) = contexts_on_one_device(gpu, oracle, 1)
+    comm = GpuComm([p])
+    assert comm.backend == "rccl" and len(comm) == 1
+    moduli, n = p.moduli(), p.ring_dimension()
+    x = np.ascontiguousarray(rand_matrix(oracle, 900 + rows, rows, max(shards[0], 1), moduli, n)[:, : shards[0]])
+    local = gpu.GpuDCRTPolyMatrix.from_rns(p, x, eval_format)
+    if shards[0]:
+        local.ntt_all_in_place() if not eval_format else local.intt_all_in_place()  # work in flight on the stream
+        local.ntt_all_in_place() if eval_format else local.intt_all_in_place()
+    (full,) = comm.all_gather_columns([local])
+    del local  # stream-ordered free right after the call
+    assert full.is_ntt == eval_format and full.ncol == shards[0]
+    assert np.array_equal(full.to_rns(), x)
+    if shards[0]:  # the C-side tag travelled too: a format-checked entry point agrees with the Python flag
+        other = gpu.GpuDCRTPolyMatrix.from_rns(p, x, eval_format)
+        assert full == other
+    comm.close()
+
+
+@pytest.mark.parametrize("copy_form", ["runtime", "kernel"])
+@pytest.mark.parametrize("rows,shards,eval_format", [(1, [2, 2], True), (1, [3, 1], False), (3, [2, 3, 1], True),
+                                                      (2, [0, 4, 2], False), (22, [4, 3], True)])
+def test_all_gather_columns_contexts_sharing_a_device(gpu, oracle, monkeypatch, rows, shards, eval_format, copy_form):
+    """Several contexts (streams, allocators) on the one device: even, uneven and empty shards, one and many rows, both
+    formats; the pull runs as runtime 2-D copies and as the copy kernel that crosses xGMI on a multi-GPU node."""
+    from mxx_amd.parallel import GpuComm
+
+    monkeypatch.setenv("MXX_HIP_COMM_COPY", copy_form)
+    ps = contexts_on_one_device(gpu, oracle, len(shards))
+    comm = GpuComm(ps)
+    assert comm.backend == "peer"
+    moduli, n = ps[0].moduli(), ps[0].ring_dimension()
+    total = sum(shards)
+    x = rand_matrix(oracle, 950 + rows + total, rows, total, moduli, n)
+    want = oracle.matrix_ntt(x, moduli) if eval_format else x
+    blocks, start = [], 0
+    for p, c in zip(ps, shards):
+        b = gpu.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(x[:, start:start + c]), False)
+        if eval_format:
+            b.ntt_all_in_place()  # still in flight on this context's stream when the gather is enqueued
+        blocks.append(b)
+        start += c
+    fulls = comm.all_gather_columns(blocks)
+    from mxx_amd import _ffi
+
+    for b in blocks:  # a block may be overwritten right after the call: the readers are ordered before it
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_fill_zero(b.raw), "gpupoly_matrix_fill_zero")
+    del blocks
+    for p, f in zip(ps, fulls):
+        assert f.params is p and f.is_ntt == eval_format
+        assert np.array_equal(f.to_rns(), want)
+    comm.close()
+
+
+def test_all_gather_columns_rejects_bad_arguments(gpu, oracle):
+    from mxx_amd import _ffi
+    from mxx_amd.parallel import GpuComm
+
+    ps = contexts_on_one_device(gpu, oracle, 2)
+    comm = GpuComm(ps)
+    M = gpu.GpuDCRTPolyMatrix
+    a, b = M(ps[0], 1, 2, 2, True), M(ps[1], 1, 2, 2, False)
+    with pytest.raises(_ffi.GpuPolyError, match="different formats"):
+        comm.all_gather_columns([a, b])
+    with pytest.raises(_ffi.GpuPolyError, match="context r"):
+        comm.all_gather_columns([a, M(ps[0], 1, 2, 2, True)])
+    with pytest.raises(_ffi.GpuPolyError, match="sum of the blocks"):
+        comm.all_gather_columns([a, M(ps[1], 1, 2, 2, True)], fulls=[M(ps[0], 1, 3, 2, True), M(ps[1], 1, 4, 2, True)])
+    with pytest.raises(_ffi.GpuPolyError, match="duplicate context"):
+        GpuComm([ps[0], ps[0]])
+    other_ring = make_params(gpu, oracle, 1024, 2, 24, 12)
+    with pytest.raises(_ffi.GpuPolyError, match="different rings"):
+        GpuComm([ps[0], other_ring])
+    comm.close()
+
+
+def test_sharded_product_and_preimage_gathered_in_process(gpu, oracle):
+    """The whole sharded path without torch: B / C column blocks and target columns split by shard_range over two
+    contexts, one worker thread per context (the ABI calls release the GIL), one all-gather through the ABI; the
+    gathered product equals the oracle's, the gathered preimage satisfies A x = u."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from mxx_amd.parallel import GpuComm, all_shard_ranges
+
+    ps = contexts_on_one_device(gpu, oracle, 2, n=256, depth=2)
+    comm = GpuComm(ps)
+    moduli, n = ps[0].moduli(), 256
+    a = oracle.matrix_ntt(rand_matrix(oracle, 41, 2, 3, moduli, n), moduli)
+    b = oracle.matrix_ntt(rand_matrix(oracle, 42, 3, 5, moduli, n), moduli)
+    ranges = all_shard_ranges(5, 2)
+
+    def work(rank):
+        p, sr = ps[rank], ranges[rank]
+        ga = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+        gb = gpu.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(b[:, sr.start:sr.stop]), True)
+        return ga * gb
+
+    with ThreadPoolExecutor(2) as ex:
+        blocks = list(ex.map(work, range(2)))
+    fulls = comm.all_gather_columns(blocks)
+    want = oracle.matmul(a, b, moduli)
+    for f in fulls:
+        assert np.array_equal(f.to_rns(), want)
+    # preimage: trapdoor replicated with copy_to_context, target columns sharded
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(ps[0], 4.578)
+    td0, a0 = sampler.trapdoor(ps[0], 1)
+    tds, pubs = [td0, td0.to_params(ps[1])], [a0, a0.to_params(ps[1])]
+    target = gpu.GpuDCRTPolyUniformSampler().sample_uniform(ps[0], 1, 5, gpu.DistType.FinRingDist())
+    t_rns = target.to_rns()
+
+    def pre(rank):
+        p, sr = ps[rank], ranges[rank]
+        t = gpu.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(t_rns[:, sr.start:sr.stop]), True)
+        return sampler.preimage(p, tds[rank], pubs[rank], t)
+
+    with ThreadPoolExecutor(2) as ex:
+        xs = list(ex.map(pre, range(2)))
+    fulls = comm.all_gather_columns(xs)
+    for pub, f in zip(pubs, fulls):
+        assert f.ncol == 5 and pub * f == gpu.GpuDCRTPolyMatrix.from_rns(f.params, t_rns, True)
+    comm.close()
