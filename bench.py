@@ -53,9 +53,13 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m3a", "m3b", "m4"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
-    ap.add_argument("--gather", default="lazy", choices=["lazy", "step"],
-                    help="sharded runs: all-gather the column blocks (product, preimage) once per timed region - the consumer "
-                         "gathers when it needs the whole matrix - or after every step, overlapped with the next one")
+    ap.add_argument("--gather", default="step", choices=["lazy", "step"],
+                    help="sharded runs: all-gather the column blocks (product, preimage) after every step, overlapped with the "
+                         "next one (default: every step's result exists on every GPU), or once per timed region - the consumer "
+                         "gathers when it needs the whole matrix; the line carries the other mode's figure as `other_gather`")
+    ap.add_argument("--inproc", action="store_true",
+                    help="N>1 in ONE process, as the reference runs (a context per device, a worker thread per context, the "
+                         "exchange through gpupoly_matrix_all_gather_columns - RCCL behind the C ABI, no torch)")
     ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K steps for median / min")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per block")
@@ -102,8 +106,21 @@ def self_launch(args) -> int:
     return rc
 
 
+class InprocRank:
+    """One of N device contexts driven by ONE process (--inproc): the reference's own model (`params_for_device`,
+    src/poly/dcrt/gpu.rs:531-557; rayon over the contexts, src/sampler/trapdoor/gpu.rs:371-397).  The exchange step goes
+    through gpupoly_matrix_all_gather_columns (RCCL behind the C ABI); no torch in the process."""
+
+    inproc, active, torch, dist, backend = True, True, None, None, "inproc"
+
+    def __init__(self, world, rank, dnum=None):
+        self.world, self.rank, self.local_rank, self.dnum = world, rank, rank, dnum
+
+
 class Dist:
     """torch.distributed when the job has more than one rank (RCCL = backend "nccl" on ROCm)."""
+
+    inproc, dnum = False, None
 
     def __init__(self, args):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,7 +218,8 @@ class Workload:
         # MXX_BENCH_FORCE_DIST=1 rehearses the sharded path (partition + RCCL gather) with a world of one rank
         self.strong = args.scaling == "strong" and (d.world > 1 or d.active)
         self.params = mx.GpuDCRTPolyParams(N_RING if self.name != "m4" else 256, self.moduli(mx), self.base_bits(),
-                                           gpu_ids=[device])
+                                           gpu_ids=[device], dnum=d.dnum)
+        self.lazy_gather = args.gather == "lazy"
         self.ctx = self.params.ctx()
         self.word = self.ctx.word_bytes()
         self.device = device
@@ -322,8 +340,8 @@ class MatMul(Workload):
             sr = shard_range(c, d.world, d.rank)
             self.c_local = len(sr)
             self.b = uniform_matrix(mx, p, k, self.c_local, 5, total_cols=c, col_start=sr.start)
-            self.gather = ColumnAllGather(p, r, c, L - 1, d.torch, d.dist, self.device, slots=2)
-            self.lazy_gather = self.args.gather == "lazy"
+            # --inproc: the runner gathers through gpupoly_matrix_all_gather_columns once every rank has enqueued its step
+            self.gather = None if d.inproc else ColumnAllGather(p, r, c, L - 1, d.torch, d.dist, self.device, slots=2)
             how = ("the blocks stay sharded between steps and are all-gathered (RCCL, on the device's stream order) ONCE "
                    "per timed region, inside it - the full C is larger than what a rank reads for its product and xGMI is "
                    "~20x slower than HBM, so a consumer gathers when it needs the whole matrix (SURVEY 8e)"
@@ -338,8 +356,8 @@ class MatMul(Workload):
             self.gather = None
             self.sharding = "weak: every rank multiplies the full shape, no collective" if d.world > 1 else "single GPU"
             self.units_total = r * k * c * d.world
-        self.lazy_gather, self._ungathered = getattr(self, "lazy_gather", False), False
-        self.outs = [mx.GpuDCRTPolyMatrix(p, r, max(self.c_local, 1), L - 1, True) for _ in range(2 if self.gather else 1)]
+        self._ungathered = False
+        self.outs = [mx.GpuDCRTPolyMatrix(p, r, max(self.c_local, 1), L - 1, True) for _ in range(2 if self.strong else 1)]
         self.out = self.outs[0]
         self.units = self.units_total
         algo = float(r * k + k * self.c_local + r * self.c_local) * N_RING * L * self.word  # SURVEY 8d, this rank's launch
@@ -351,8 +369,8 @@ class MatMul(Workload):
     def step(self, i, mark):
         from mxx_amd import _ffi
 
-        per_step = self.gather is not None and not self.lazy_gather
-        slot = self.gather_begin(i) if per_step else 0
+        per_step = self.strong and not self.lazy_gather  # two output buffers: the gather of step i runs under step i + 1
+        slot = (self.gather_begin(i) if self.gather is not None else i & 1) if per_step else 0
         self.out = self.outs[slot]
         if mark:
             self.mark(i, 0)
@@ -360,14 +378,19 @@ class MatMul(Workload):
             _ffi.check_status(_ffi.lib().gpu_matrix_mul(self.out.raw, self.a.raw, self.b.raw), "gpu_matrix_mul")
         if mark:
             self.mark(i, 1)
-        if per_step:
-            self.gather_enqueue(i, slot, self.out if self.c_local else self.out.slice_columns(0, 0))
+            if i == 0:  # the roofline names what the dispatcher launched for THIS product, not a constant
+                self.launched_kernel = self.ctx.last_kernel()
+        if per_step and self.gather is not None:
+            self.gather_enqueue(i, slot, self.local_block())
         self._ungathered = True
+
+    def local_block(self):
+        return self.out if self.c_local else self.out.slice_columns(0, 0)
 
     def drain(self):
         if self.gather is not None and self.lazy_gather:
             if self._ungathered:  # the region's one exchange step
-                self.full = self.gather.gather(self.out if self.c_local else self.out.slice_columns(0, 0))
+                self.full = self.gather.gather(self.local_block())
                 self._ungathered = False
             return
         super().drain()
@@ -379,21 +402,23 @@ class MatMul(Workload):
         if col is not None:
             one = self.a * col
             assert one == self.out.slice_columns(0, 1), "product column differs between kernel paths"
-        if self.gather is not None and self.c_local:  # the gathered matrix holds this rank's block where it belongs
+        if self.strong and self.full is not None and self.c_local:  # the gathered matrix holds this rank's block where it belongs
             from mxx_amd.parallel import shard_range
 
             sr = shard_range(self.shape[2], self.d.world, self.d.rank)
+            assert self.full.ncol == self.shape[2], "gathered product has the wrong width"
             assert self.full.slice_columns(sr.start, sr.stop) == self.out, "gathered product block differs"
+
 
 
 class M2A(MatMul):
     name, depth, shape = "m2a", 15, (1, 30, 120)
-    kernel_label = "matmul_kernel<u32,1,8,4> (R_q matrix product, skinny: B streamed once)"
+    kernel_label = "R_q matrix product (skinny: B streamed once)"  # replaced by gpupoly_context_last_kernel() after the first step
 
 
 class M2B(MatMul):
     name, depth, shape = "m2b", 8, (64, 64, 64)
-    kernel_label = "fat R_q matrix product (mmfma / mmdma kernel, see config.matmul_path)"
+    kernel_label = "R_q matrix product (fat)"
 
 
 class Preimage(Workload):
@@ -416,8 +441,8 @@ class Preimage(Workload):
             sr = shard_range(self.cols, d.world, d.rank)
             self.c_local = len(sr)
             self.target = uniform_matrix(mx, p, self.dsize, self.c_local, 9, total_cols=self.cols, col_start=sr.start)
-            self.gather = ColumnAllGather(p, (k + 2) * self.dsize, self.cols, self.depth - 1, d.torch, d.dist, self.device, slots=2)
-            self.lazy_gather = self.args.gather == "lazy"
+            self.out_rows = (k + 2) * self.dsize
+            self.gather = None if d.inproc else ColumnAllGather(p, self.out_rows, self.cols, self.depth - 1, d.torch, d.dist, self.device, slots=2)
             how = ("the preimage blocks stay on the device that sampled them between calls (the reference's fan-out, "
                    "src/sampler/trapdoor/gpu.rs:371-397, never moves them device to device) and are all-gathered (RCCL, on the "
                    "device's stream order) ONCE per timed region, inside it - a rank's block is 98 MB per call at N=8, an "
@@ -439,7 +464,7 @@ class Preimage(Workload):
         self.x = None
 
     def step(self, i, mark):
-        per_call = self.gather is not None and not getattr(self, "lazy_gather", False)
+        per_call = self.gather is not None and not self.lazy_gather
         slot = self.gather_begin(i) if per_call else 0
         if mark:
             self.mark(i, 0)
@@ -447,16 +472,19 @@ class Preimage(Workload):
             self.x = self.sampler.preimage(self.params, self.td, self.pub, self.target)
         if mark:
             self.mark(i, 1)
-        if self.gather is not None:
+        if self.strong:
             if not self.c_local:
-                self.x = self.mx.GpuDCRTPolyMatrix(self.params, self.gather.rows, 0, self.depth - 1, True)
+                self.x = self.mx.GpuDCRTPolyMatrix(self.params, self.out_rows, 0, self.depth - 1, True)
             if per_call:
                 self.gather_enqueue(i, slot, self.x)
             else:
                 self._ungathered = True
 
+    def local_block(self):
+        return self.x
+
     def drain(self):
-        if self.gather is not None and getattr(self, "lazy_gather", False):
+        if self.gather is not None and self.lazy_gather:
             if getattr(self, "_ungathered", False):  # the region's one exchange step
                 self.full = self.gather.gather(self.x)
                 self._ungathered = False
@@ -466,10 +494,11 @@ class Preimage(Workload):
     def check(self):
         if self.c_local:
             assert self.pub * self.x == self.target, "A*x != u"
-        if self.gather is not None and self.c_local:
+        if self.strong and self.full is not None and self.c_local:
             from mxx_amd.parallel import shard_range
 
             sr = shard_range(self.cols, self.d.world, self.d.rank)
+            assert self.full.ncol == self.cols, "gathered preimage has the wrong width"
             assert self.full.slice_columns(sr.start, sr.stop) == self.x, "gathered preimage block differs"
 
 
@@ -566,9 +595,28 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
         wl.drain()
         d.barrier_sync(mx.gpu_device_sync)
         reps.append(d.max_over_ranks(time.perf_counter() - t1) * 1e3 / steps)
+    other = None
+    if wl.gather is not None and hasattr(wl, "lazy_gather"):
+        # the same K steps under the other exchange policy (per step <-> once per region), so that the line shows what the
+        # choice is worth; `value` above is the policy named in the top-level "gather" field
+        wl.lazy_gather = not wl.lazy_gather
+        wl.step(0, False)
+        wl.drain()
+        d.barrier_sync(mx.gpu_device_sync)
+        t2 = time.perf_counter()
+        for i in range(steps):
+            wl.step(i, False)
+        wl.drain()
+        d.barrier_sync(mx.gpu_device_sync)
+        dt = d.max_over_ranks(time.perf_counter() - t2)
+        other = {"gather": "lazy" if wl.lazy_gather else "step", "ms_per_step": dt * 1e3 / steps, "value": wl.units * steps / dt}
+        wl.lazy_gather = not wl.lazy_gather
+        wl.step(0, False)
+        wl.drain()
     wl.check()
     all_ms = [elapsed * 1e3 / steps] + reps
     return {
+        "other_gather": other,
         "elapsed_s": elapsed,
         "ms_per_step": elapsed * 1e3 / steps,
         "value": wl.units * steps / elapsed,
@@ -587,17 +635,23 @@ def roofline_of(wl: Workload, kernel_ms):
         return {"bound": "hbm", "kernel": label, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                 "traffic": None, "kernel_ms": round(ms, 4)}
     ms, label, algo = max(cands)
+    label = getattr(wl, "launched_kernel", None) or label
     achieved = algo / (ms * 1e-3) / 1e9
-    traffic = None
+    traffic = source = None
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{wl.name}.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and wl.d.world == 1:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tpath))
+            traffic = rec.get("hbm_bytes_per_launch")
+            # PMC counters need their own rocprofv3 passes (the guide's HBM section): the figure is read from the committed
+            # summary of the same command, not measured in this run
+            source = f"profiles/pmc_traffic_{wl.name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload {wl.name}`, " \
+                     f"kernel {rec.get('kernel', '?')})"
         except Exception:
-            traffic = None
+            traffic = source = None
     return {"bound": "hbm", "kernel": label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": algo,
-            "kernel_ms": round(ms, 5)}
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes_per_launch": algo, "kernel_ms": round(ms, 5)}
 
 
 def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
@@ -612,6 +666,11 @@ def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
         "higher_is_better": True,
         # the mode of the N-sweep this line belongs to (the same at N = 1): "strong" where the workload splits one problem
         "scaling": args.scaling if isinstance(wl, (MatMul, Preimage)) else "weak",
+        # sharded runs: "step" = the column blocks are all-gathered after EVERY step (overlapped with the next one), "lazy" =
+        # once per timed region; null where nothing is exchanged (N = 1, weak scaling, independent batches)
+        "gather": args.gather if getattr(wl, "strong", False) and isinstance(wl, (MatMul, Preimage)) else None,
+        "other_gather": res.get("other_gather"),
+        "launch": ("one process, N contexts (gpupoly_comm)" if d.inproc else "one process per GPU (torch.distributed)") if d.world > 1 or d.active else "single process",
         "vs_baseline": None,
         "dtype": "u32" if wl.word == 4 else "u64",
         "data": "synthetic",
@@ -640,9 +699,121 @@ def kernels_block(m1: Workload, res):
     return out
 
 
+def run_block_inproc(mx, wls, comm, steps, warmup, repeats):
+    """run_block for N contexts of one process: a worker thread per context issues that context's steps (the ABI calls
+    release the GIL and never block), a barrier per step lets one thread enqueue the step's all-gather through the C ABI
+    once every context has enqueued its block; ONE host clock around the region, every device synchronised on both sides."""
+    import threading
+
+    n = len(wls)
+    fulls = {}
+
+    def gather(slot):
+        fulls[slot] = comm.all_gather_columns([wl.local_block() for wl in wls], fulls.get(slot))
+        for wl, f in zip(wls, fulls[slot]):
+            wl.full = f
+
+    def region(k, mark):
+        per_step = comm is not None and not wls[0].lazy_gather
+        start, step_barrier, errors = threading.Barrier(n + 1), threading.Barrier(n), []
+
+        def body(r):
+            try:
+                start.wait()
+                for i in range(k):
+                    wls[r].step(i, mark)
+                    if per_step:
+                        step_barrier.wait()
+                        if r == 0:
+                            gather(i & 1)
+            except BaseException as e:  # noqa: BLE001 - reported by the main thread
+                errors.append(e)
+                step_barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(n)]
+        for t in threads:
+            t.start()
+        mx.gpu_device_sync()
+        t0 = time.perf_counter()
+        start.wait()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        if comm is not None and not per_step and k:
+            gather(0)  # the region's one exchange step
+        mx.gpu_device_sync()
+        return time.perf_counter() - t0
+
+    for wl in wls:
+        for i in range(steps):
+            for j in range(wl.nmarks):
+                wl.mark(i, j)
+    region(max(warmup, 1), False)
+    elapsed = region(steps, True)
+    kernel_ms = wls[0].kernel_ms(steps)
+    reps = [region(steps, False) * 1e3 / steps for _ in range(repeats)]
+    other = None
+    if comm is not None:
+        for wl in wls:
+            wl.lazy_gather = not wl.lazy_gather
+        region(1, False)
+        dt = region(steps, False)
+        other = {"gather": "lazy" if wls[0].lazy_gather else "step", "ms_per_step": dt * 1e3 / steps, "value": wls[0].units * steps / dt}
+        for wl in wls:
+            wl.lazy_gather = not wl.lazy_gather
+        region(1, False)
+    for wl in wls:
+        wl.check()
+    all_ms = [elapsed * 1e3 / steps] + reps
+    return {"other_gather": other, "elapsed_s": elapsed, "ms_per_step": elapsed * 1e3 / steps, "value": wls[0].units * steps / elapsed,
+            "kernel_ms": kernel_ms,
+            "repeats": {"count": len(all_ms), "steps_each": steps, "median_ms_per_step": statistics.median(all_ms),
+                        "min_ms_per_step": min(all_ms), "max_ms_per_step": max(all_ms),
+                        "value_at_median": wls[0].units / (statistics.median(all_ms) * 1e-3)}}
+
+
+def main_inproc(args, emit):
+    import mxx_amd as mx
+    from mxx_amd.parallel import GpuComm
+
+    n, ndev = args.gpus, mx.detected_gpu_device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    share = ndev < n
+    if share and os.environ.get("MXX_BENCH_INPROC_SHARE_DEVICES") != "1":
+        raise SystemExit(f"bench.py --inproc: {n} contexts need {n} devices, {ndev} visible "
+                         "(MXX_BENCH_INPROC_SHARE_DEVICES=1 rehearses the path with contexts sharing devices - not a measurement)")
+    ranks = [InprocRank(n, r, 7000 + r if share else None) for r in range(n)]
+
+    def run(name, repeats):
+        wls = [WORKLOADS[name](mx, ranks[r], args, r % ndev) for r in range(n)]
+        for wl in wls:
+            wl.setup()
+        comm = GpuComm([wl.params for wl in wls]) if wls[0].strong and isinstance(wls[0], (MatMul, Preimage)) else None
+        res = run_block_inproc(mx, wls, comm, args.steps, args.warmup, repeats)
+        line = block_json(wls[0], res, ranks[0], args, args.steps, args.warmup)
+        line["config"]["comm_backend"] = comm.backend if comm is not None else None
+        line["config"]["devices"] = [r % ndev for r in range(n)]
+        if comm is not None:
+            comm.close()
+        return line
+
+    if args.workload == "default":
+        line = run("m2a", args.repeats)
+        pre = run("m3a", min(args.repeats, 3))
+        for key in ("n_gpus", "higher_is_better", "vs_baseline", "data", "scaling", "roofline"):
+            pre.pop(key, None)
+        line["preimage"] = pre
+    else:
+        line = run(args.workload, args.repeats)
+    line["cpu_baseline"] = None  # an N = 1 leg (run `python bench.py`)
+    emit(line)
+
+
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inproc:
         sys.exit(self_launch(args))  # nothing GPU-related has been imported or called in this process
 
     # stdout carries exactly ONE JSON line: native libraries write banners to file descriptor 1 (RCCL prints its
@@ -654,6 +825,8 @@ def main():
     def emit(obj):
         os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
+    if args.inproc and "WORLD_SIZE" not in os.environ:
+        return main_inproc(args, emit)
     d = Dist(args)
     if args.dry_run:
         ok = 1.0

@@ -207,6 +207,9 @@ int gpupoly_matrix_device_ptr(const GpuMatrix *mat, void **out_ptr, size_t *out_
 int gpupoly_matrix_copy_to_context(GpuContext *dst_ctx, const GpuMatrix *src, GpuMatrix **out);
 int gpupoly_context_device(const GpuContext *ctx, int *out_device);
 int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes);
+/* name of the product kernel the dispatcher launched for the last gpu_matrix_mul on this context (bench.py labels its
+ * roofline with what actually ran); "" before the first product                                                  */
+const char *gpupoly_context_last_kernel(const GpuContext *ctx);
 /* the context's compute stream (hipStream_t): lets the host order collectives against engine work on the device */
 int gpupoly_context_stream(const GpuContext *ctx, void **out_stream);
 /* ---- multi-GPU exchange, one process / N device contexts ----------------------------------------

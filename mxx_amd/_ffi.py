@@ -114,6 +114,7 @@ SIGNATURES = {
     "gpupoly_matrix_copy_to_context": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "gpupoly_context_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_context_word_bytes": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gpupoly_context_last_kernel": (C.c_char_p, [_vp]),
     "gpupoly_context_stream": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "gpupoly_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(_vp)]),
     "gpupoly_comm_destroy": (None, [_vp]),

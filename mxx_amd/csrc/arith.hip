@@ -439,6 +439,7 @@ static int launch_matmul_lds_u32(GpuMatrix *out, const GpuMatrix *lhs, const Gpu
     const uint64_t blocks = groups * row_tiles * col_tiles;
     if (blocks > 0x7fffffffull) return set_error("gpu_matrix_mul: matrix too large");
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
+    ctx->last_kernel = "matmul_lds_kernel_u32 (64 slots x 16x16 tile, operands staged through registers into LDS)";
     hipLaunchKernelGGL(matmul_lds_kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
@@ -458,10 +459,17 @@ static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatr
     const uint32_t gx = (N / SV + threads - 1) / threads;
     if (static_cast<uint64_t>(row_tiles) * col_tiles > 65535) return set_error("gpu_matrix_mul: matrix too large");
     dim3 grid(gx, row_tiles * col_tiles, L);
+    const bool nt = row_tiles == 1 && rhs->bytes > (size_t(1) << 28);
+    static const std::string name[2] = {
+        std::string("matmul_kernel<") + (sizeof(W) == 4 ? "u32," : "u64,") + std::to_string(TR) + "," + std::to_string(TC) + "," +
+            std::to_string(SV) + (PF ? ",loads-ahead" : "") + "> (register tile rows x cols x slots per lane)",
+        std::string("matmul_kernel<") + (sizeof(W) == 4 ? "u32," : "u64,") + std::to_string(TR) + "," + std::to_string(TC) + "," +
+            std::to_string(SV) + (PF ? ",loads-ahead" : "") + ",nt> (register tile rows x cols x slots per lane, B streamed once with non-temporal loads)"};
+    ctx->last_kernel = name[nt ? 1 : 0].c_str();
     // B is read by this one row tile only and cannot live in the 256 MB Infinity Cache: streamed with non-temporal loads
     // (a smaller B is often re-used from cache by the next product - the hint made repeated products on a 134 MB operand
     // 40 % slower)
-    if (row_tiles == 1 && rhs->bytes > (size_t(1) << 28))
+    if (nt)
         hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, true>), grid, dim3(threads), 0, ctx->stream,
                            static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
                            static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -85,6 +86,9 @@ struct GpuContext {
     std::multimap<size_t, void *> free_blocks;      // size -> block
     std::unordered_map<void *, size_t> live_blocks;  // block -> size
     size_t cached_bytes = 0, cache_limit = 0;
+    // name of the kernel the product dispatcher launched last on this context (a string literal or a function-local
+    // static: bench.py labels its roofline with what actually ran, gpupoly_context_last_kernel)
+    std::atomic<const char *> last_kernel{""};
 };
 
 struct GpuMatrix {
@@ -141,8 +145,25 @@ int set_error(hipError_t err, const char *what);
         if (_e != hipSuccess) return set_error(_e, #expr);     \
     } while (0)
 
+// roctx range around an ABI entry (rocprofv3 --marker-trace attributes kernels to the FFI call that launched them).
+// Active under rocprofv3 (ROCP_TOOL_LIBRARIES is set by it) or with MXX_HIP_ROCTX=1; one predictable branch otherwise.
+extern int (*g_roctx_push)(const char *);
+extern int (*g_roctx_pop)();
+void roctx_init_once();
+struct RoctxScope {
+    bool on;
+    explicit RoctxScope(const char *name) {
+        roctx_init_once();
+        on = g_roctx_push != nullptr;
+        if (on) g_roctx_push(name);
+    }
+    ~RoctxScope() {
+        if (on) g_roctx_pop();
+    }
+};
+
 // every extern "C" body is wrapped so no exception crosses the ABI
-#define ABI_GUARD_BEGIN try {
+#define ABI_GUARD_BEGIN try { RoctxScope roctx_scope_(__func__);
 #define ABI_GUARD_END                                                         \
     }                                                                         \
     catch (const std::exception &e) { return set_error(e.what()); }           \

@@ -416,6 +416,7 @@ int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatri
         configured.fetch_or(bit);
     }
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
+    ctx->last_kernel = "mmdma32::kernel_u32 (32 slots x 32x32 tile, 16 waves, global_load_lds four-stage ring)";
     hipLaunchKernelGGL(mmdma32::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(1024), mmdma32::LDS_BYTES, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
@@ -444,6 +445,7 @@ int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix 
         configured.fetch_or(bit);
     }
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
+    ctx->last_kernel = "mmdma::kernel_u32 (64 slots x 32x16 tile, 8 waves, global_load_lds three-stage ring)";
     hipLaunchKernelGGL(mmdma::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(512), mmdma::LDS_BYTES, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,

@@ -232,25 +232,36 @@ int launch_matmul_mfma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix
     static std::atomic<uint64_t> configured{0};
     const uint64_t bit = 1ull << (ctx->device & 63);
     if (!(configured.load() & bit)) {
+#ifdef GPUPOLY_PHASE_TIMING
         const void *fns[] = {reinterpret_cast<const void *>(mmfma::kernel_u32<0>), reinterpret_cast<const void *>(mmfma::kernel_u32<1>),
                              reinterpret_cast<const void *>(mmfma::kernel_u32<2>)};
+#else
+        const void *fns[] = {reinterpret_cast<const void *>(mmfma::kernel_u32<0>)};
+#endif
         for (const void *fn : fns)
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mmfma::LDS_BYTES)));
         configured.fetch_or(bit);
     }
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
-    static const int mode = [] {  // phase-timing builds of the same kernel (results are wrong for mode != 0)
-        const char *e = std::getenv("MXX_HIP_MFMA_MODE");
-        return e ? std::atoi(e) : 0;
-    }();
+    ctx->last_kernel = "mmfma::kernel_u32 (16 slots x 32x32 tile, 9 v_mfma_i32_32x32x32_i8 per 32-deep chunk on balanced int8 digits)";
 #define MMFMA_LAUNCH(M)                                                                                                   \
     hipLaunchKernelGGL(mmfma::kernel_u32<M>, dim3(static_cast<unsigned>(blocks)), dim3(mmfma::THREADS), mmfma::LDS_BYTES, \
                        ctx->stream, static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),          \
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,        \
                        col_tiles, slot_chunks, remap)
+#ifdef GPUPOLY_PHASE_TIMING
+    // phase-timing builds of the same kernel for tools/time_mfma_phases.py (make PHASE_TIMING=1): modes 1 and 2 skip
+    // phases and produce WRONG results, so they do not exist in the shipped library
+    static const int mode = [] {
+        const char *e = std::getenv("MXX_HIP_MFMA_MODE");
+        return e ? std::atoi(e) : 0;
+    }();
     if (mode == 1) MMFMA_LAUNCH(1);
-    else if (mode == 2) MMFMA_LAUNCH(2);
+    else if (mode == 2 && out->bytes >= size_t(1024) * mmfma::THREADS * 4) MMFMA_LAUNCH(2);  // mode 2 writes 1024 x THREADS words of C
     else MMFMA_LAUNCH(0);
+#else
+    MMFMA_LAUNCH(0);
+#endif
 #undef MMFMA_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;

@@ -109,6 +109,23 @@ __host__ __device__ __forceinline__ void chacha_set_stream(uint32_t (&state)[16]
     state[15] = (static_cast<uint32_t>(stream0 >> 32) & 0xffffu) | (static_cast<uint32_t>(stream1 >> 32) << 16);
 }
 
+// One keystream block of stream (stream0, stream1) under `key`, entirely in registers: 8 little-endian u64 words.
+// The block-per-8-draws samplers (uniform, bit, ternary) use it: no ring, no LDS.
+__host__ __device__ __forceinline__ void chacha_block_words(const ChaChaKey &key, uint64_t stream0, uint64_t stream1, uint32_t block,
+                                                            uint64_t (&out)[8]) {
+    uint32_t st[16], x[16];
+    st[0] = 0x61707865u; st[1] = 0x3320646eu; st[2] = 0x79622d32u; st[3] = 0x6b206574u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[4 + i] = key.w[i];
+    chacha_set_stream(st, stream0, stream1, block);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = st[i];
+    chacha_rounds<10>(x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        out[i] = static_cast<uint64_t>(x[2 * i] + st[2 * i]) | (static_cast<uint64_t>(x[2 * i + 1] + st[2 * i + 1]) << 32);
+}
+
 __device__ __forceinline__ void rng_init_keyed(ChaChaRng &rng, uint64_t *ring_base, const ChaChaKey &key,
                                                uint64_t stream0, uint64_t stream1) {
     rng.state[0] = 0x61707865u; rng.state[1] = 0x3320646eu; rng.state[2] = 0x79622d32u; rng.state[3] = 0x6b206574u;

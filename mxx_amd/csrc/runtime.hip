@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <iterator>
 #include <cstring>
+#include <dlfcn.h>
 
 typedef unsigned __int128 u128h;
 
@@ -31,6 +32,29 @@ int set_error(hipError_t err, const char *what) {
 extern "C" const char *gpu_last_error(void) { return g_last_error.c_str(); }
 extern "C" int gpu_set_last_error(const char *msg) { return set_error(msg); }
 extern "C" const char *gpupoly_version(void) { return "gpupoly-mi355x 0.1 (gfx950)"; }
+
+// ---- roctx (tracing) ---------------------------------------------------------------
+int (*g_roctx_push)(const char *) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+void roctx_init_once() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *sw = std::getenv("MXX_HIP_ROCTX");
+        const bool profiled = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr || std::getenv("ROCPROFILER_REGISTER_FORCE_LOAD") != nullptr;
+        if (sw ? sw[0] == '0' : !profiled) return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            auto push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            auto pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) {
+                g_roctx_pop = pop;
+                g_roctx_push = push;
+                return;
+            }
+        }
+    });
+}
 
 // ---- host number theory ---------------------------------------------------------
 static inline uint64_t h_mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128h)a * b) % q); }
@@ -466,6 +490,9 @@ extern "C" int gpupoly_context_stream(const GpuContext *ctx, void **out_stream) 
     *out_stream = static_cast<void *>(ctx->stream);
     return 0;
 }
+
+// the product kernel the dispatcher chose for the last gpu_matrix_mul on this context ("" before the first one)
+extern "C" const char *gpupoly_context_last_kernel(const GpuContext *ctx) { return ctx ? ctx->last_kernel.load() : ""; }
 
 extern "C" int gpupoly_context_word_bytes(const GpuContext *ctx, int *out_bytes) {
     if (!ctx || !out_bytes) return set_error("gpupoly_context_word_bytes: null argument");

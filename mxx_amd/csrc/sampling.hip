@@ -2,13 +2,15 @@
 // Replaces cuda/src/matrix/MatrixSampling.cu behind
 // cuda/include/matrix/MatrixSampling.cuh:25-37.
 //
-// Every coefficient owns a ChaCha20 stream keyed by the GLOBAL polynomial index
-// row*full_ncol + col (+1), the coefficient index (+1) and, for the uniform
-// distribution, the limb index (+1): sample_distribution_columns therefore equals
-// the matching column slice of the full sample for the same seed
-// (reference: MatrixSampling.cu:232-289, test src/sampler/gpu.rs:323-361).
-// One thread draws the integer once and writes its residue into every limb (the
-// reference relaunches per limb and redraws); the result is transformed to EVAL.
+// Every sample is a pure function of (seed, GLOBAL polynomial index row*full_ncol + col,
+// coefficient index and, for the uniform distribution, limb index):
+// sample_distribution_columns therefore equals the matching column slice of the full
+// sample for the same seed (reference: MatrixSampling.cu:232-289, test
+// src/sampler/gpu.rs:323-361).  Gaussian: a ChaCha20 stream per coefficient (Karney's
+// sampler draws a variable number of words).  Uniform / bit / ternary: fixed-position
+// draws, eight per keystream block (the reference's keying, one stream - i.e. at least
+// one block - per residue, made the generator the whole cost of the call).  Integers are
+// drawn once and written as residues into every limb; the result is transformed to EVAL.
 #include "common.h"
 #include "modarith.h"
 #include "rng.h"
@@ -20,45 +22,121 @@ static constexpr uint64_t kTagGauss = 0x6f70656e66686532ull;
 static constexpr uint64_t kTagBit = 0x6f70656e66686533ull;
 static constexpr uint64_t kTagTernary = 0x6f70656e66686534ull;
 
-// uniform / bit / ternary: one short stream per coefficient (and per limb for uniform).  The
-// HChaCha20 sub-keys depend on the limb only, so the block derives them once into LDS.
+// uniform / bit / ternary: ONE ChaCha20 block serves eight draws (round 2 spent a block per residue: 25 ms for M2A's
+// 3.5 GB operand, 0.02 of the HBM roofline, with the generator as the whole cost).  Keying, a pure function of
+// (seed, global polynomial index, limb, coefficient) as before, so column windows commute (src/sampler/gpu.rs:323-361):
+//   uniform : sub-key = HChaCha20(seed, tag, stream2 = limb + 1); residue of coefficient i = word (i & 7) of keystream
+//             block (i >> 3) of stream (gpoly + 1, 0), reduced mod q when it is below floor(2^64 / q) q; a rejected
+//             word (probability q 2^-64) is replaced by the first accepted word of the coefficient's own overflow
+//             stream (gpoly + 1, i + 1) under the same sub-key;
+//   bit / ternary : sub-key (seed, tag, 0); the draw of coefficient i = the same word of stream (gpoly + 1, 0).
+// A thread owns eight consecutive coefficients of one (polynomial, limb) vector: one block in registers, no LDS, and
+// 32 / 64 contiguous bytes stored per lane.  The sub-keys are derived once per call by a one-wave launch.
+__global__ void derive_subkeys_kernel(ChaChaKey *__restrict__ keys, GpuRngSeed seed, uint64_t tag, uint32_t count, uint32_t first_stream2) {
+    const uint32_t l = threadIdx.x;
+    if (l < count) keys[l] = chacha_subkey(seed, static_cast<uint64_t>(first_stream2) + l, tag);
+}
+
+__device__ __forceinline__ ChaChaKey load_key(const ChaChaKey *__restrict__ keys, uint32_t l) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(keys + l);
+    const uint4 a = p[0], b = p[1];
+    ChaChaKey k;
+    k.w[0] = a.x; k.w[1] = a.y; k.w[2] = a.z; k.w[3] = a.w;
+    k.w[4] = b.x; k.w[5] = b.y; k.w[6] = b.z; k.w[7] = b.w;
+    return k;
+}
+
+// the rare path of the uniform sampler: first accepted word of the coefficient's overflow stream
+__device__ __noinline__ uint64_t uniform_overflow_draw(const ChaChaKey &key, uint64_t stream0, uint64_t stream1, uint64_t threshold) {
+    for (uint32_t block = 0;; ++block) {
+        uint64_t w[8];
+        chacha_block_words(key, stream0, stream1, block, w);
+        for (int j = 0; j < 8; ++j)
+            if (w[j] < threshold) return w[j];
+    }
+}
+
+template <typename W, int VEC>
+__device__ __forceinline__ void store_group(W *dst, const W (&r)[8], uint32_t count) {
+    if (count == 8 && VEC) {
+        typedef W vec_t __attribute__((ext_vector_type(16 / sizeof(W))));
+        constexpr int per = 16 / sizeof(W);
+#pragma unroll
+        for (int v = 0; v < 8 / per; ++v) {
+            vec_t x;
+#pragma unroll
+            for (int e = 0; e < per; ++e) x[e] = r[v * per + e];
+            __builtin_nontemporal_store(x, reinterpret_cast<vec_t *>(dst) + v);
+        }
+    } else {
+        for (uint32_t j = 0; j < count; ++j) dst[j] = r[j];
+    }
+}
+
 template <typename W>
-__global__ void __launch_bounds__(256) sample_distribution_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
-                                           size_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L,
-                                           uint32_t N, int dist, GpuRngSeed seed) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
-    __shared__ ChaChaKey keys[GPUPOLY_MAX_LIMBS];
-    const bool uniform = dist == GPU_MATRIX_DIST_UNIFORM;
-    if (threadIdx.x < (uniform ? L : 1u))
-        keys[threadIdx.x] = uniform ? chacha_subkey(seed, static_cast<uint64_t>(threadIdx.x) + 1, kTagUniform)
-                                    : chacha_subkey(seed, 0, dist == GPU_MATRIX_DIST_BIT ? kTagBit : kTagTernary);
-    __syncthreads();
+__global__ void __launch_bounds__(256) sample_uniform_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs,
+                                                             const ChaChaKey *__restrict__ keys, size_t polys, size_t local_ncol,
+                                                             size_t full_ncol, size_t col_offset, uint32_t L, uint32_t N,
+                                                             uint32_t groups /* ceil(N / 8) */) {
     const size_t idx = item_index();
-    if (idx >= polys * N) return;
-    const size_t p = idx / N;
-    const uint32_t i = static_cast<uint32_t>(idx - p * N);
+    if (idx >= polys * L * groups) return;
+    const size_t vec = idx / groups;  // (polynomial, limb) vector
+    const uint32_t g = static_cast<uint32_t>(idx - vec * groups);
+    const size_t p = vec / L;
+    const uint32_t l = static_cast<uint32_t>(vec - p * L);
     const size_t row = p / local_ncol, lcol = p - row * local_ncol;
     const uint64_t gpoly = row * full_ncol + col_offset + lcol;
-    W *dst = out + p * L * N + i;
-    ChaChaRng rng;
-    if (uniform) {
-        for (uint32_t l = 0; l < L; ++l) {
-            rng_init_keyed(rng, ring, keys[l], gpoly + 1, static_cast<uint64_t>(i) + 1);
-            dst[static_cast<size_t>(l) * N] = static_cast<W>(rng_uniform_mod(rng, limbs[l].q));
+    const ChaChaKey key = load_key(keys, l);
+    const uint64_t q = limbs[l].q, mu64 = limbs[l].mu64;
+    const uint64_t threshold = mu64 * q;  // = (2^64 - 1) - (2^64 - 1) % q: q is an odd prime, so floor((2^64-1)/q) = floor(2^64/q)
+    uint64_t w[8];
+    chacha_block_words(key, gpoly + 1, 0, g, w);
+    const uint32_t count = min(8u, N - g * 8u);
+    W r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint64_t x = w[j];
+        if (x >= threshold && static_cast<uint32_t>(j) < count) x = uniform_overflow_draw(key, gpoly + 1, static_cast<uint64_t>(g) * 8u + j + 1, threshold);
+        uint64_t rem = x - __umul64hi(x, mu64) * q;  // quotient estimate at most one short
+        rem = rem >= q ? rem - q : rem;
+        r[j] = static_cast<W>(rem);
+    }
+    store_group<W, 1>(out + vec * N + static_cast<size_t>(g) * 8u, r, count);
+}
+
+// bit / ternary: the draw is shared by all limbs
+template <typename W>
+__global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs,
+                                                           const ChaChaKey *__restrict__ keys, size_t polys, size_t local_ncol,
+                                                           size_t full_ncol, size_t col_offset, uint32_t L, uint32_t N, uint32_t groups,
+                                                           int dist) {
+    const size_t idx = item_index();
+    if (idx >= polys * groups) return;
+    const size_t p = idx / groups;
+    const uint32_t g = static_cast<uint32_t>(idx - p * groups);
+    const size_t row = p / local_ncol, lcol = p - row * local_ncol;
+    const uint64_t gpoly = row * full_ncol + col_offset + lcol;
+    const ChaChaKey key = load_key(keys, 0);
+    uint64_t w[8];
+    chacha_block_words(key, gpoly + 1, 0, g, w);
+    const uint32_t count = min(8u, N - g * 8u);
+    int32_t z[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (dist == GPU_MATRIX_DIST_BIT) {
+            z[j] = static_cast<int32_t>(w[j] & 1ull);
+        } else {
+            const uint32_t pick = static_cast<uint32_t>(w[j] % 3ull);
+            z[j] = pick == 0 ? 0 : (pick == 1 ? 1 : -1);
         }
-        return;
     }
-    rng_init_keyed(rng, ring, keys[0], gpoly + 1, static_cast<uint64_t>(i) + 1);
-    rng_fill(rng);
-    int64_t z;
-    if (dist == GPU_MATRIX_DIST_BIT) {
-        z = static_cast<int64_t>(rng_next_u64(rng) & 1ull);
-    } else {
-        const uint64_t pick = rng_next_u64(rng) % 3ull;
-        z = pick == 0 ? 0 : (pick == 1 ? 1 : -1);
+    for (uint32_t l = 0; l < L; ++l) {
+        const W q = static_cast<W>(limbs[l].q);
+        W r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = z[j] < 0 ? q - 1 : static_cast<W>(z[j]);
+        store_group<W, 1>(out + (p * L + l) * N + static_cast<size_t>(g) * 8u, r, count);
     }
-    for (uint32_t l = 0; l < L; ++l)
-        dst[static_cast<size_t>(l) * N] = signed_to_residue_mu<W>(z, limbs[l].q, limbs[l].mu64);
 }
 
 // discrete Gaussian: persistent lanes (rng.h).  Wave w owns coefficients [w*64*per_lane, +64*per_lane);
@@ -140,15 +218,28 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         HIP_TRY(err);
         if (rc) return rc;
     } else {
-        const dim3 blocks = item_grid(total, 256);
-        if (ctx->wide)
-            hipLaunchKernelGGL(sample_distribution_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               static_cast<uint64_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
-                               L, N, dist, seed);
-        else
-            hipLaunchKernelGGL(sample_distribution_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               static_cast<uint32_t *>(out->data), ctx->d_limbs, polys, out->cols, full_ncol, col_offset,
-                               L, N, dist, seed);
+        const bool uniform = dist == GPU_MATRIX_DIST_UNIFORM;
+        const uint32_t groups = (N + 7) / 8;
+        const uint32_t nkeys = uniform ? L : 1u;
+        CtxBlock keys(ctx);  // per call: concurrent callers on one context must not share a key table
+        if (keys.alloc(sizeof(ChaChaKey) * nkeys)) return 1;
+        ChaChaKey *d_keys = static_cast<ChaChaKey *>(keys.ptr);
+        const uint64_t tag = uniform ? kTagUniform : (dist == GPU_MATRIX_DIST_BIT ? kTagBit : kTagTernary);
+        hipLaunchKernelGGL(derive_subkeys_kernel, dim3(1), dim3(64), 0, ctx->stream, d_keys, seed, tag, nkeys, uniform ? 1u : 0u);
+        HIP_TRY(hipGetLastError());
+        const size_t threads = polys * (uniform ? L : 1u) * groups;
+        const dim3 blocks = item_grid(threads, 256);
+#define MXX_SAMPLE(KERNEL, WORD, ...)                                                                                     \
+    hipLaunchKernelGGL(KERNEL<WORD>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<WORD *>(out->data), ctx->d_limbs, \
+                       d_keys, polys, out->cols, full_ncol, col_offset, L, N, groups, ##__VA_ARGS__)
+        if (uniform) {
+            if (ctx->wide) MXX_SAMPLE(sample_uniform_kernel, uint64_t);
+            else MXX_SAMPLE(sample_uniform_kernel, uint32_t);
+        } else {
+            if (ctx->wide) MXX_SAMPLE(sample_small_kernel, uint64_t, dist);
+            else MXX_SAMPLE(sample_small_kernel, uint32_t, dist);
+        }
+#undef MXX_SAMPLE
     }
     HIP_TRY(hipGetLastError());
     if (keep_coeff) return 0;

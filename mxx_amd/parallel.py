@@ -183,6 +183,11 @@ class ColumnAllGather:
             for r, sr in enumerate(self.ranges):
                 if len(sr):
                     s["full"].copy_block_from(s["recv"], 0, sr.start, r * self.rows, 0, self.rows, len(sr))
+        # RCCL moved raw bytes and copy_block propagated recv's tag: retag the C side from `local` (a zero-sized block copy
+        # carries the source's format to the whole destination and moves nothing), then the Python mirror
+        from . import _ffi
+
+        _ffi.check_status(_ffi.lib().gpu_matrix_copy_block(s["full"].raw, local.raw, 0, 0, 0, 0, 0, 0), "gpu_matrix_copy_block")
         s["full"].is_ntt = local.is_ntt
         return s["full"]
 

@@ -147,6 +147,10 @@ class GpuContext:
         _ffi.check_status(_ffi.lib().gpupoly_context_stream(self.raw, C.byref(h)), "gpupoly_context_stream")
         return h.value or 0
 
+    def last_kernel(self) -> str:
+        """Name of the product kernel the dispatcher launched last on this context."""
+        return (_ffi.lib().gpupoly_context_last_kernel(self.raw) or b"").decode()
+
     def word_bytes(self) -> int:
         d = C.c_int(0)
         _ffi.check_status(_ffi.lib().gpupoly_context_word_bytes(self.raw, C.byref(d)), "gpupoly_context_word_bytes")

@@ -19,9 +19,27 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_SAN_PATH = os.path.join(_HERE, "liboracle_asan.so")
+_CFLAGS = ["-fopenmp", "-fPIC", "-std=gnu11", "-ffp-contract=off"]  # oracle/Makefile builds with the same flags
+
+
+def build_sanitized() -> str:
+    """AddressSanitizer + UndefinedBehaviorSanitizer build of the same sources (the reference runs
+    its native code under sanitizers on the CPU).  tests/test_oracle_sanitized.py re-runs the oracle's own CPU tests on
+    it in a child process (MXX_ORACLE_LIB selects the library, libasan is preloaded)."""
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle_sampling.c")]
+    deps = srcs + [os.path.join(_HERE, "..", "mxx_amd", "csrc", "detmath.h")]
+    if not os.path.exists(_SAN_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_SAN_PATH) for s in deps):
+        subprocess.check_call(
+            ["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+            + _CFLAGS + ["-shared", "-o", _SAN_PATH] + srcs + ["-lm"]
+        )
+    return _SAN_PATH
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("MXX_ORACLE_LIB"):  # a prebuilt variant (the sanitizer build) chosen by the caller
+        return os.environ["MXX_ORACLE_LIB"]
     srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle_sampling.c")]
     deps = srcs + [os.path.join(_HERE, "..", "mxx_amd", "csrc", "detmath.h")]  # Box-Muller's log / cos, shared text
     if (
@@ -30,7 +48,7 @@ def build(force: bool = False) -> str:
         or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in deps)
     ):
         subprocess.check_call(
-            ["gcc", "-O3", "-fopenmp", "-fPIC", "-std=gnu11", "-ffp-contract=off", "-shared", "-o", _LIB_PATH]
+            ["gcc", "-O3"] + _CFLAGS + ["-shared", "-o", _LIB_PATH]
             + srcs
             + ["-lm"]
         )
@@ -46,6 +64,7 @@ def use_native_build() -> str:
 
     if "liboracle_native" in _LIB_PATH:
         return _LIB_PATH
+    os.environ.pop("MXX_ORACLE_LIB", None)  # the timed baseline is never the sanitizer build
     if _lib is not None:
         raise RuntimeError("use_native_build() must run before the library is first loaded")
     out = os.path.join(tempfile.mkdtemp(prefix="oracle_native_"), "liboracle_native.so")
@@ -67,8 +86,7 @@ _i64p = C.POINTER(C.c_int64)
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        _lib = C.CDLL(build())
         L = _lib
         L.orc_mulmod.restype = C.c_uint64
         L.orc_mulmod.argtypes = [C.c_uint64] * 3

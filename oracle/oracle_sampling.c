@@ -113,13 +113,6 @@ static double std_normal(rng_t *r) {
     return sqrt(-2.0 * det_log(u1)) * det_cos2pi(u2);
 }
 
-static uint64_t uniform_mod(rng_t *r, uint64_t q) {
-    const uint64_t max = ~0ull, threshold = max - (max % q);
-    for (;;) {
-        uint64_t x = rng_u64(r);
-        if (x < threshold) return x % q;
-    }
-}
 
 /* Karney, "Sampling exactly from the normal distribution" (arXiv:1303.6257), algorithm D */
 static int k_h(rng_t *r) {
@@ -196,8 +189,23 @@ void orc_karney(const uint64_t *seed, uint64_t s0, double mean, double stddev, i
     for (size_t i = 0; i < count; ++i) out[i] = karney(&r, mean, stddev);
 }
 
+/* word (i & 7) of keystream block (i >> 3) of stream (s0, 0): the fixed-position draw of coefficient i
+ * (mxx_amd/csrc/sampling.hip: one ChaCha20 block serves eight draws) */
+static uint64_t positional_word(const uint64_t *seed, uint64_t s0, uint64_t s2, uint64_t tag, uint32_t i) {
+    rng_t r;
+    rng_init(&r, seed, s0, 0, s2, tag);
+    r.state[12] = i >> 3;
+    orc_chacha20_block(r.state, r.block);
+    const uint32_t j = i & 7u;
+    return (uint64_t)r.block[2 * j] | ((uint64_t)r.block[2 * j + 1] << 32);
+}
+
 /* Coefficient-domain samples of a rows x local_ncol window at column offset col_offset of a
- * rows x full_ncol matrix; out layout [poly][limb][n].  dist: 0 uniform, 1 gauss, 2 bit, 3 ternary. */
+ * rows x full_ncol matrix; out layout [poly][limb][n].  dist: 0 uniform, 1 gauss, 2 bit, 3 ternary.
+ * Keying as in mxx_amd/csrc/sampling.hip (the reference's, cuda/src/matrix/MatrixSampling.cu:239-289, spends a
+ * stream per residue): uniform = positional word of stream (gpoly + 1, 0) under sub-key (tag, limb + 1), rejected
+ * words replaced by the first accepted word of the overflow stream (gpoly + 1, i + 1); bit / ternary = the
+ * positional word under sub-key (tag, 0); Gaussian = Karney on the coefficient's own stream (gpoly + 1, i + 1). */
 void orc_sample_distribution(uint64_t *out, size_t rows, size_t local_ncol, size_t full_ncol, size_t col_offset,
                              uint32_t L, uint32_t n, const uint64_t *moduli, int dist, double sigma,
                              const uint64_t *seed) {
@@ -210,8 +218,13 @@ void orc_sample_distribution(uint64_t *out, size_t rows, size_t local_ncol, size
             rng_t r;
             if (dist == 0) {
                 for (uint32_t l = 0; l < L; ++l) {
-                    rng_init(&r, seed, gpoly + 1, (uint64_t)i + 1, (uint64_t)l + 1, 0x6f70656e66686531ull);
-                    out[((size_t)p * L + l) * n + i] = uniform_mod(&r, moduli[l]);
+                    const uint64_t q = moduli[l], max = ~0ull, threshold = max - (max % q);
+                    uint64_t x = positional_word(seed, gpoly + 1, (uint64_t)l + 1, 0x6f70656e66686531ull, i);
+                    if (x >= threshold) {
+                        rng_init(&r, seed, gpoly + 1, (uint64_t)i + 1, (uint64_t)l + 1, 0x6f70656e66686531ull);
+                        do x = rng_u64(&r); while (x >= threshold);
+                    }
+                    out[((size_t)p * L + l) * n + i] = x % q;
                 }
                 continue;
             }
@@ -220,11 +233,9 @@ void orc_sample_distribution(uint64_t *out, size_t rows, size_t local_ncol, size
                 rng_init(&r, seed, gpoly + 1, (uint64_t)i + 1, 0, 0x6f70656e66686532ull);
                 z = karney(&r, 0.0, sigma);
             } else if (dist == 2) {
-                rng_init(&r, seed, gpoly + 1, (uint64_t)i + 1, 0, 0x6f70656e66686533ull);
-                z = (int64_t)(rng_u64(&r) & 1ull);
+                z = (int64_t)(positional_word(seed, gpoly + 1, 0, 0x6f70656e66686533ull, i) & 1ull);
             } else {
-                rng_init(&r, seed, gpoly + 1, (uint64_t)i + 1, 0, 0x6f70656e66686534ull);
-                uint64_t pick = rng_u64(&r) % 3ull;
+                uint64_t pick = positional_word(seed, gpoly + 1, 0, 0x6f70656e66686534ull, i) % 3ull;
                 z = pick == 0 ? 0 : (pick == 1 ? 1 : -1);
             }
             for (uint32_t l = 0; l < L; ++l) out[((size_t)p * L + l) * n + i] = signed_mod(z, moduli[l]);

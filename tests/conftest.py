@@ -90,3 +90,39 @@ def make_params(gpu_mod, oracle_mod, n, depth, bits, base_bits):
 
 def rand_matrix(oracle_mod, seed, rows, cols, moduli, n):
     return oracle_mod.random_matrix(seed, rows, cols, moduli, n)
+
+
+def is_prime(n: int) -> bool:
+    """Deterministic Miller-Rabin for n < 2^64."""
+    if n < 2:
+        return False
+    for b in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % b == 0:
+            return n == b
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    for b in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(b, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def high_rejection_moduli(n: int, count: int) -> list:
+    """Primes = 1 (mod 2n) just below 2^64 / 4.5: 2^64 mod q is about q / 2, so one 64-bit draw in nine is
+    rejected by the uniform sampler (24-bit limbs reject one in 2^40: their overflow path would never run in a test)."""
+    out, q = [], (1 << 64) * 2 // 9
+    q -= (q - 1) % (2 * n)
+    while len(out) < count:
+        if is_prime(q):
+            out.append(q)
+        q -= 2 * n
+    return out

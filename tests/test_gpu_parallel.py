@@ -95,6 +95,11 @@ CHILD_GATHER = textwrap.dedent(
         assert len(fulls) == 6
         for i, (f, w) in enumerate(zip(fulls, want)):
             assert f == w, ("gathered product differs", rows, i)
+        # a COEFF block: both sides of the ABI must carry the tag (ensure_eval would otherwise transform nothing)
+        c = O.random_matrix(330 + rows, rows, 5, moduli, n)
+        got = g.gather(mx.GpuDCRTPolyMatrix.from_rns(p, c, False))
+        assert not got.is_ntt and got == mx.GpuDCRTPolyMatrix.from_rns(p, c, False), ("COEFF gather", rows)
+        assert np.array_equal(got.ensure_eval().to_rns(), O.matrix_ntt(c, moduli)), ("COEFF gather, then NTT", rows)
     dist.destroy_process_group()
     print("RCCL_PIPELINED_GATHER_OK")
     """

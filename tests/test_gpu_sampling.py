@@ -25,7 +25,25 @@ def seed(gpu, salt=0):
     return gpu.GpuRngSeed.from_bytes(bytes(b))
 
 
-@pytest.mark.parametrize("n,depth,bits,base", [(16, 3, 18, 6), (128, 2, 17, 1), (1024, 2, 24, 12), (64, 2, 51, 17)])
+def test_uniform_sampler_overflow_streams_bit_exact(gpu, oracle):
+    """Moduli that reject one 64-bit draw in nine: the rare path of the block-per-eight-draws uniform sampler (the
+    coefficient's overflow stream) runs hundreds of times and must agree with the CPU restatement; windows commute."""
+    from conftest import high_rejection_moduli
+
+    n = 256
+    moduli = high_rejection_moduli(n, 3)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 20)
+    s = seed(gpu, 9)
+    code = oracle.DIST["uniform"]
+    m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, code, 0.0, s)
+    want = oracle.sample_distribution(2, 3, moduli, n, "uniform", 0.0, s)
+    assert np.array_equal(m.to_coeff_rns(), want)
+    w = gpu.GpuDCRTPolyMatrix.sample_distribution_columns(p, 2, 3, 2, 1, code, 0.0, s)
+    assert np.array_equal(w.to_coeff_rns(), want[:, 2:3])
+
+
+@pytest.mark.parametrize("n,depth,bits,base", [(4, 2, 17, 1), (16, 3, 18, 6), (128, 2, 17, 1), (1024, 2, 24, 12), (64, 2, 51, 17),
+                                               (16384, 2, 24, 12)])
 @pytest.mark.parametrize("dist,sigma", [("uniform", 0.0), ("gauss", 4.578), ("gauss", 321.7), ("bit", 0.0), ("ternary", 0.0)])
 def test_sample_distribution_bit_exact(gpu, oracle, n, depth, bits, base, dist, sigma):
     p = make_params(gpu, oracle, n, depth, bits, base)

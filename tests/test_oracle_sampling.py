@@ -97,6 +97,39 @@ def test_distribution_sampler_properties_and_windows():
     assert np.abs(c).max() < 6 * 3.2 and abs(c.std() - 3.2) < 0.3  # |x| < 6 sigma (sampler/gpu.rs:363-400)
 
 
+def test_uniform_sampler_keying_and_overflow_streams():
+    """One keystream block serves eight uniform draws: the residue of coefficient i of limb l is word i of stream
+    (gpoly + 1, 0) under sub-key (tag, l + 1); a rejected word is replaced by the first accepted word of the overflow
+    stream (gpoly + 1, i + 1).  Recomputed here from raw keystream words, with moduli that reject one draw in nine."""
+    from conftest import high_rejection_moduli
+
+    n, tag = 16, 0x6f70656e66686531
+    moduli = high_rejection_moduli(n, 2)
+    rows, cols, full, off = 2, 2, 5, 3
+    got = O.sample_distribution(rows, cols, moduli, n, "uniform", 0, SEED, full_ncol=full, col_offset=off)
+    rejected = 0
+    for r in range(rows):
+        for c in range(cols):
+            gpoly = r * full + off + c
+            for l, q in enumerate(moduli):
+                thr = (2**64 - 1) - (2**64 - 1) % q
+                words = O.rng_stream(SEED, gpoly + 1, 0, l + 1, tag, n)
+                for i in range(n):
+                    x = int(words[i])
+                    if x >= thr:
+                        rejected += 1
+                        x = next(int(w) for w in O.rng_stream(SEED, gpoly + 1, i + 1, l + 1, tag, 64) if int(w) < thr)
+                    assert int(got[r, c, l, i]) == x % q
+    assert rejected >= 3, "the overflow path was not exercised"
+    # bit / ternary: the same positional word under sub-key (tag, 0), shared by all limbs
+    for dist, t in (("bit", 0x6f70656e66686533), ("ternary", 0x6f70656e66686534)):
+        s = O.sample_distribution(1, 1, moduli, n, dist, 0, SEED)
+        words = O.rng_stream(SEED, 1, 0, 0, t, n)
+        for i in range(n):
+            z = int(words[i]) & 1 if dist == "bit" else (0, 1, -1)[int(words[i]) % 3]
+            assert [int(v) for v in s[0, 0, :, i]] == [z % q for q in moduli]
+
+
 @pytest.mark.parametrize("n,depth,bits,base", [(16, 2, 17, 1), (16, 2, 16, 4), (16, 3, 17, 5), (8, 2, 51, 17), (16, 2, 24, 12)])
 def test_g_sampler_relation_on_cpu(n, depth, bits, base):
     """G * gauss_samp_gq(M) == M (gpu_dcrt_poly.rs:2381-2542)."""

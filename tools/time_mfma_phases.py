@@ -1,5 +1,7 @@
 """Phase timing of the matrix-core product (matmul_mfma.hip) at M2b: full kernel, without global loads,
-loads + conversion only, without the byte split.  Run once per mode: MXX_HIP_MFMA_MODE=m python tools/time_mfma_phases.py"""
+loads + conversion only, without the byte split.  Run once per mode: MXX_HIP_MFMA_MODE=m python tools/time_mfma_phases.py
+Needs a library built with `make -C mxx_amd/csrc PHASE_TIMING=1` (modes 1 and 2 produce wrong results by design and are
+not compiled into the shipped library)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mxx_amd as mx
