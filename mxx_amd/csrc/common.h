@@ -64,6 +64,8 @@ struct GpuContext {
     hipStream_t stream = nullptr;
     // device tables
     LimbConst *d_limbs = nullptr;  // [limb_count]
+    LimbConst *d_limbs_r = nullptr;  // u32 words: the same with n_inv / inv_last_w (+ companions) multiplied by 2^32 mod q,
+                                     // for the inverse transform that multiplies in its load (Montgomery product, ntt14.h)
     void *d_tw_fwd = nullptr;      // [limb][N] words, fwd[bitrev(i)] = psi^i
     void *d_tw_fwd_sh = nullptr;   // Shoup companions
     void *d_tw_inv = nullptr;      // inv[bitrev(i)] = psi^-i

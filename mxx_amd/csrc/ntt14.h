@@ -193,14 +193,19 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
 }
 
 // SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)
-// MULW: the transform's load multiplies by a resident EVAL-form ring element first (mulw = {w, Shoup(w)} per
-// limb and slot, `in` = the EVAL operand): data <- INTT(in o w) with one kernel instead of a point-wise pass
-// (a full HBM round trip) followed by the transform - gpupoly_matrix_mul_scalar_intt.
+// MULW: the transform's load multiplies by a resident EVAL-form ring element first (mulw = its residues [limb][N],
+// `in` = the EVAL operand): data <- INTT(in o w) with one kernel instead of a point-wise pass (a full HBM round trip)
+// followed by the transform - gpupoly_matrix_mul_scalar_intt.  The product is a Montgomery one, REDC(x w) =
+// x w 2^-32 (three multiply-class instructions, like a Shoup product, but on the plain 4-byte residue of w: round 2's
+// Shoup pairs were 8 bytes per element - twice the data's own bytes, built by an extra launch - and their loads sat
+// on the critical path of every group: 169 us against 120 for the plain inverse).  The missing factor 2^32 is folded
+// into the last stage's constants: the MULW launch passes ctx->d_limbs_r, whose n_inv / inv_last_w are multiplied by
+// 2^32 mod q.  PF: the next group's operands are requested before this group's butterflies start.
 // CAP: bound-exponent cap of the unsigned butterflies (kTightCap for 26..28-bit moduli, ntt_lds.h)
-template <typename W, bool SGN, bool MULW = false, int CAP = 31>
-__global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
+template <typename W, bool SGN, bool MULW = false, int CAP = 31, int WPS = ((SGN && !MULW) ? 8 : 6)>
+__global__ void __launch_bounds__(512, WPS / (sizeof(W) / 4))
     inv_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
-               uint32_t L, const W *in = nullptr, const TwPair<W> *__restrict__ mulw = nullptr) {
+               uint32_t L, const W *in = nullptr, const W *__restrict__ mulw = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *xs = reinterpret_cast<W *>(smem);
     typedef typename std::conditional<sizeof(W) == 4, uint4, ulonglong2>::type V16;
@@ -215,6 +220,18 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
     const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
     W *g = data + vec * N;
 
+    // MULW: operands of the group after the current one, requested a group ahead
+    V16 dnext[8 / VN], wnext[8 / VN];
+    const W *src0 = (MULW ? in + vec * N : g) + wave * BLK + 8 * lane;
+    const W *wsrc0 = MULW ? mulw + static_cast<size_t>(limb) * N + wave * BLK + 8 * lane : nullptr;
+    if constexpr (MULW) {
+#pragma unroll
+        for (int m = 0; m < 8 / VN; ++m) {
+            dnext[m] = *reinterpret_cast<const V16 *>(src0 + m * VN);
+            wnext[m] = *reinterpret_cast<const V16 *>(wsrc0 + m * VN);
+        }
+    }
+
     W h[R0];
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
@@ -223,17 +240,28 @@ __global__ void __launch_bounds__(512, (SGN ? 8 : 6) / (sizeof(W) / 4))
         const uint32_t B = 8u * grp + wave;
         W v[8];
         {   // stages 13,12,11 on 8 contiguous words per lane, straight from HBM
-            const W *src = (MULW ? in + vec * N : g) + B * BLK + 8 * lane;
-#pragma unroll
-            for (int m = 0; m < 8; m += VN) *reinterpret_cast<V16 *>(&v[m]) = *reinterpret_cast<const V16 *>(src + m);
             if constexpr (MULW) {
-                const TwPair<W> *wp = mulw + static_cast<size_t>(limb) * N + B * BLK + 8 * lane;
-                TwPair<W> wv[8];
+                static_assert(sizeof(W) == 4, "the fused product is a 32-bit Montgomery product");
+                W wv[8];
 #pragma unroll
-                for (int m = 0; m < 8; m += VN / 2)
-                    *reinterpret_cast<V16 *>(&wv[m]) = *reinterpret_cast<const V16 *>(wp + m);
+                for (int m = 0; m < 8 / VN; ++m) {
+                    *reinterpret_cast<V16 *>(&v[m * VN]) = dnext[m];
+                    *reinterpret_cast<V16 *>(&wv[m * VN]) = wnext[m];
+                }
+                if (grp < 3) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = mul_shoup<W>(v[m], wv[m].w, wv[m].ws, q);  // canonical, as loaded
+                    for (int m = 0; m < 8 / VN; ++m) {
+                        dnext[m] = *reinterpret_cast<const V16 *>(src0 + (grp + 1) * 8 * BLK + m * VN);
+                        wnext[m] = *reinterpret_cast<const V16 *>(wsrc0 + (grp + 1) * 8 * BLK + m * VN);
+                    }
+                }
+                const W qninv = neg_inv_pow2<W>(q);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = csub<W>(mont_mul_lazy(v[m], wv[m], q, qninv), q);  // canonical, as a load would give
+            } else {
+                const W *src = g + B * BLK + 8 * lane;
+#pragma unroll
+                for (int m = 0; m < 8; m += VN) *reinterpret_cast<V16 *>(&v[m]) = *reinterpret_cast<const V16 *>(src + m);
             }
             if constexpr (SGN) {  // canonical inputs (exponent 0); keep exponents <= 2
                 gs_network_signed<3, false>(v, tw, B * 64u + lane, 11, q, lc);

@@ -87,6 +87,24 @@ __device__ __forceinline__ W fold_2q(W x, W q, W muw) {
     return x + mulhi_w(x, muw) * opaque_neg<W>(q);
 }
 
+
+// ---- Montgomery product for a transform whose load multiplies by a resident ring element (MULW forms) ---------------
+// REDC(a b) = a b 2^-32 (mod q) in [0, 2q): three multiply-class instructions, like a Shoup product, but on the plain
+// 4-byte residue of the multiplier (no companion table).  The kernels that use it read the N^-1 constants from
+// ctx->d_limbs_r, where they carry the compensating factor 2^32.
+template <typename W>
+__device__ __forceinline__ W neg_inv_pow2(W q) {  // -q^-1 mod 2^bits(W), q odd: Newton, 3 -> 6 -> 12 -> 24 -> 48 -> 96 bits
+    W x = q;
+#pragma unroll
+    for (int i = 0; i < (sizeof(W) == 4 ? 4 : 5); ++i) x *= static_cast<W>(2) - q * x;
+    return static_cast<W>(0) - x;
+}
+__device__ __forceinline__ uint32_t mont_mul_lazy(uint32_t a, uint32_t b, uint32_t q, uint32_t qninv) {
+    const uint64_t p = static_cast<uint64_t>(a) * b;          // a b < q 2^32
+    const uint32_t m = static_cast<uint32_t>(p) * qninv;
+    return static_cast<uint32_t>((p + static_cast<uint64_t>(m) * q) >> 32);
+}
+
 // ---- forward pass: stages [S_P, S_P + C), Cooley-Tukey, values grow by 2q per stage --------
 template <typename W, int C>
 __device__ __forceinline__ void ct_network_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p,
@@ -415,10 +433,12 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
 }
 
 // PRE > 0: the last PRE stages (and the N^-1 scaling) are left to ntt_inv_tail_kernel; outputs stay below 2q
-template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false, bool NT = false>
+// MULW: data <- INTT(in o w), w = the residues [limb][2^(LOGN + PRE)] of a resident EVAL-form ring element, multiplied in
+// the load (Montgomery product; `limbs` = ctx->d_limbs_r here, or in the tail kernel when PRE > 0)
+template <typename W, int LOGN, int LOGR, int WAVES_PER_EU, int PRE = 0, bool TIGHT = false, bool NT = false, bool MULW = false>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     ntt_inv_lazy_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
-                        uint32_t L) {
+                        uint32_t L, const W *in = nullptr, const W *__restrict__ mulw = nullptr) {
     typedef NttLdsCfg<W, LOGN, LOGR, true> Cfg;
     constexpr uint32_t N = Cfg::N, T = Cfg::T;
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
@@ -438,10 +458,27 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
 
     // HBM -> LDS, 16 bytes per lane
     constexpr int VN = 16 / sizeof(W);
+    if constexpr (MULW) {
+        static_assert(sizeof(W) == 4, "the fused product is a 32-bit Montgomery product");
+        const W *src = in + (g - data);
+        const W *wsrc = mulw + (static_cast<size_t>(limb) << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
+        const W qninv = neg_inv_pow2<W>(q);
 #pragma unroll
-    for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
-        const uint32_t i = tid + jj * T;
-        nt_load16<NT, W>(&x[lds_pad_c(i * VN)], g + static_cast<size_t>(i) * VN);
+        for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
+            const uint32_t i = tid + jj * T;
+            W d[VN], wv[VN];
+            nt_load16<NT, W>(d, src + static_cast<size_t>(i) * VN);
+            nt_load16<false, W>(wv, wsrc + static_cast<size_t>(i) * VN);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) d[e] = csub<W>(mont_mul_lazy(d[e], wv[e], q, qninv), q);  // canonical, as a load would give
+            nt_load16<false, W>(&x[lds_pad_c(i * VN)], d);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t jj = 0; jj < N / VN / T; ++jj) {
+            const uint32_t i = tid + jj * T;
+            nt_load16<NT, W>(&x[lds_pad_c(i * VN)], g + static_cast<size_t>(i) * VN);
+        }
     }
     __syncthreads();
     {   // contiguous pass: stages [2 LOGR, LOGN) in GS order

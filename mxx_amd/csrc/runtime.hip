@@ -306,6 +306,7 @@ static void context_release(GpuContext *ctx) {
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
     for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->d_limbs) (void)hipFree(ctx->d_limbs);
+    if (ctx->d_limbs_r) (void)hipFree(ctx->d_limbs_r);
     if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
     if (ctx->d_tw_fwd_sh) (void)hipFree(ctx->d_tw_fwd_sh);
     if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);
@@ -447,6 +448,18 @@ extern "C" int gpu_context_create(uint32_t logN, uint32_t L, uint32_t dnum, cons
     if (e == hipSuccess)
         e = hipMemcpy(ctx->d_garner, ctx->garner_inv.data(), sizeof(uint64_t) * moduli_len * moduli_len,
                       hipMemcpyHostToDevice);
+    if (e == hipSuccess && !wide) {
+        std::vector<LimbConst> lr = ctx->limbs;
+        for (LimbConst &c : lr) {
+            const uint64_t r = (1ull << 32) % c.q;
+            c.n_inv = h_mulmod(c.n_inv, r, c.q);
+            c.n_inv_sh = static_cast<uint64_t>(((u128h)c.n_inv << 32) / c.q);
+            c.inv_last_w = h_mulmod(c.inv_last_w, r, c.q);
+            c.inv_last_w_sh = static_cast<uint64_t>(((u128h)c.inv_last_w << 32) / c.q);
+        }
+        e = hipMalloc(&ctx->d_limbs_r, sizeof(LimbConst) * moduli_len);
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_limbs_r, lr.data(), sizeof(LimbConst) * moduli_len, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) rc = set_error(e, "context constant upload");
     if (!rc) rc = wide ? upload_tables<uint64_t>(ctx, fwd, inv) : upload_tables<uint32_t>(ctx, fwd, inv);
     if (!rc) {

@@ -10,7 +10,7 @@ from conftest import make_params, rand_matrix
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("depth", [3, 6])
+@pytest.mark.parametrize("depth", [3, 6, 12])  # 12: tests/test_gpu_ggh15_modp_chain.rs:36-42, what `bench.py --workload m4` times
 def test_preimage_mul_decompose_chain_u64(gpu, oracle, depth):
     n, bits, base, d = 256, 51, 17, 2
     p = make_params(gpu, oracle, n, depth, bits, base)

@@ -51,6 +51,46 @@ def test_m2b_gadget_inverse_and_associativity(gpu, oracle):
     assert int(d_small.max()) < (1 << 12)
 
 
+def test_m2a_output_columns_against_the_oracle(gpu, oracle):
+    """The bench shape's product, three of its 120 output columns recomputed by the CPU restatement (30 ring products
+    each, all 15 limbs): an error shared by both sides of an algebraic identity - a wrong per-limb constant at L = 15,
+    say - cannot hide here."""
+    p = make_params(gpu, oracle, N, 15, 24, 12)
+    moduli = p.moduli()
+    us = gpu.GpuDCRTPolyUniformSampler()
+    a = us.sample_uniform(p, 1, 30, gpu.DistType.FinRingDist())
+    b = us.sample_uniform(p, 30, 120, gpu.DistType.FinRingDist())
+    c = a * b
+    assert "matmul_kernel<u32,1,8,4" in p.ctx().last_kernel()  # the kernel bench.py times
+    a_h = a.to_rns()
+    for col in (0, 57, 119):
+        want = oracle.matmul(a_h, b.slice_columns(col, col + 1).to_rns(), moduli)
+        assert np.array_equal(c.slice_columns(col, col + 1).to_rns(), want), col
+
+
+def test_m2b_entries_and_decompose_rows_against_the_oracle(gpu, oracle):
+    """64^3 at L = 8 through the streamed product: three output entries (64 ring products each) against the CPU
+    restatement; and one source entry of the 64 x 64 -> 1024 x 64 decomposition (its 16 digit polynomials, EVAL form)
+    against oracle.decompose + oracle NTT."""
+    p = make_params(gpu, oracle, N, 8, 24, 12)
+    moduli = p.moduli()
+    us = gpu.GpuDCRTPolyUniformSampler()
+    a = us.sample_uniform(p, 64, 64, gpu.DistType.FinRingDist())
+    b = us.sample_uniform(p, 64, 64, gpu.DistType.FinRingDist())
+    c = a * b
+    assert "mmdma32" in p.ctx().last_kernel()
+    for r, col in ((0, 0), (37, 21), (63, 63)):
+        want = oracle.matmul(a.slice_rows(r, r + 1).to_rns(), b.slice_columns(col, col + 1).to_rns(), moduli)
+        assert np.array_equal(c.slice(r, r + 1, col, col + 1).to_rns(), want), (r, col)
+    k = p.modulus_digits()
+    dec = a.decompose()
+    for r, col in ((0, 0), (41, 63)):
+        src = oracle.matrix_ntt(a.slice(r, r + 1, col, col + 1).to_rns(), moduli, inverse=True)
+        want = oracle.matrix_ntt(oracle.decompose(src, moduli, 12), moduli)
+        assert want.shape[0] == k
+        assert np.array_equal(dec.slice(r * k, (r + 1) * k, col, col + 1).to_rns(), want), (r, col)
+
+
 @pytest.mark.parametrize("depth", [10, 8])  # bench_preimage_gpu.rs shape (M3a) and BASELINE configs[3] (M3b, L = 8)
 def test_m3_preimage_relation_and_norm(gpu, oracle, depth):
     p = make_params(gpu, oracle, N, depth, 24, 12)

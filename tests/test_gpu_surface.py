@@ -192,11 +192,16 @@ def test_copy_to_context_and_sharded_preimages_two_contexts_one_device(gpu, orac
 
 
 @pytest.mark.parametrize("n,depth,bits,design", [(16384, 3, 24, "grouped"), (16384, 2, 24, "unsigned"), (16384, 2, 25, "grouped"),
-                                                 (16384, 2, 24, "whole"), (1024, 2, 24, "grouped"), (256, 2, 51, "grouped")])
+                                                 (16384, 2, 24, "whole"), (16384, 2, 28, "grouped"), (1024, 2, 24, "grouped"),
+                                                 (2048, 2, 28, "grouped"), (4096, 3, 24, "grouped"), (8192, 2, 27, "grouped"),
+                                                 (32768, 2, 24, "grouped"), (65536, 2, 28, "grouped"), (65536, 2, 24, "grouped"),
+                                                 (131072, 2, 28, "grouped"), (512, 2, 24, "grouped"), (256, 2, 51, "grouped")])
 def test_mul_scalar_intt_fused(gpu, oracle, hip_env, n, depth, bits, design):
-    """gpupoly_matrix_mul_scalar_intt: INTT(x o w) with the product in the inverse transform's load (2^14-point
-    u32 kernels, signed and unsigned butterflies) and its two-call fallback elsewhere - bit-exact against
-    the CPU restatement, out-of-place and in place."""
+    """gpupoly_matrix_mul_scalar_intt: INTT(x o w) with the product (a Montgomery one, on w's plain residues) in the
+    inverse transform's load: the grouped 2^14 kernels (signed and unsigned butterflies), every whole-vector LDS kernel
+    (2^10..2^15, lazy and 26..28-bit TIGHT forms), the split 2^16 / 2^17 kernels (the reference's end-to-end ring,
+    tests/test_gpu_diamond_io.rs:64-71) - and the two-call fallback elsewhere (n < 2^10, 64-bit words).  Bit-exact
+    against the CPU restatement, out-of-place and in place."""
     from mxx_amd import _ffi
 
     hip_env.set("MXX_HIP_NTT14", design)
