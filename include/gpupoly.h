@@ -156,6 +156,25 @@ int gpupoly_matrix_mul_decompose(GpuMatrix *out, const GpuMatrix *lhs, const Gpu
  * up to 64 per launch; large ones run one by one through the tuned kernels.  No output may be another product's
  * operand.  (the reference issues one call per gate, src/circuit/poly_circuit/eval.rs:269.)        */
 int gpupoly_matrix_mul_batch(GpuMatrix *const *outs, const GpuMatrix *const *lhss, const GpuMatrix *const *rhss, size_t count);
+/* A level of independent circuit gates in one call (the reference issues one ABI call per gate,
+ * src/circuit/poly_circuit/eval.rs:269-345): products go out up to 64 per launch (gpupoly_matrix_mul_batch), the
+ * point-wise gates - add, sub, negate, product by a 1x1 ring element (Small / LargeScalarMul) - up to 64 per launch,
+ * decompositions through their tuned paths.  One context; no output may be another gate's operand or output; formats
+ * and shapes as for the single-gate entry points named below.                                                      */
+#define GPUPOLY_OP_MUL 0           /* gpu_matrix_mul(out, lhs, rhs) */
+#define GPUPOLY_OP_ADD 1           /* gpu_matrix_add(out, lhs, rhs); out may be lhs */
+#define GPUPOLY_OP_SUB 2           /* gpu_matrix_sub */
+#define GPUPOLY_OP_MUL_SCALAR 3    /* gpu_matrix_mul_scalar(out, lhs, rhs = 1x1) */
+#define GPUPOLY_OP_NEG 4           /* gpupoly_matrix_neg(out, lhs); rhs ignored */
+#define GPUPOLY_OP_DECOMPOSE 5     /* gpu_matrix_decompose_base(lhs, base_bits, out); rhs ignored */
+#define GPUPOLY_OP_MUL_DECOMPOSE 6 /* gpupoly_matrix_mul_decompose(out, lhs, rhs, base_bits) */
+typedef struct GpuBatchOp {
+    int kind;
+    GpuMatrix *out;
+    const GpuMatrix *lhs;
+    const GpuMatrix *rhs;
+} GpuBatchOp;
+int gpupoly_batch(const GpuBatchOp *ops, size_t count, uint32_t base_bits);
 /* lhs * small-G^-1(rhs) (digits of limb 0 only): replaces the column-chunk loop of mul_decompose_small
  * (src/matrix/gpu_dcrt_poly.rs:1495-1574).                                                                */
 int gpupoly_matrix_mul_decompose_small(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs, uint32_t base_bits);

@@ -43,6 +43,14 @@ class GpuRngSeed(C.Structure):
         return b"".join(int(w).to_bytes(8, "little") for w in self.words)
 
 
+class GpuBatchOp(C.Structure):
+    """`struct GpuBatchOp { int kind; GpuMatrix *out; const GpuMatrix *lhs, *rhs; }` (include/gpupoly.h)."""
+
+    _fields_ = [("kind", C.c_int), ("out", C.c_void_p), ("lhs", C.c_void_p), ("rhs", C.c_void_p)]
+
+
+GPUPOLY_OP_MUL, GPUPOLY_OP_ADD, GPUPOLY_OP_SUB, GPUPOLY_OP_MUL_SCALAR, GPUPOLY_OP_NEG, GPUPOLY_OP_DECOMPOSE, GPUPOLY_OP_MUL_DECOMPOSE = range(7)
+
 _vp = C.c_void_p
 _sz = C.c_size_t
 _u8p = C.POINTER(C.c_uint8)
@@ -95,6 +103,7 @@ SIGNATURES = {
     "gpu_poly_load_compact_bytes": (C.c_int, [_vp, _vp, _sz, C.c_uint16]),
     "gpupoly_matrix_mul_decompose": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
     "gpupoly_matrix_mul_batch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t]),
+    "gpupoly_batch": (C.c_int, [C.POINTER(GpuBatchOp), C.c_size_t, C.c_uint32]),
     "gpupoly_matrix_mul_decompose_small": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
     "gpupoly_matrix_mul_tensor_identity": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "gpupoly_matrix_mul_tensor_identity_decompose": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint32]),

@@ -14,6 +14,7 @@
 #include "modarith.h"
 
 #include <algorithm>
+#include <vector>
 
 enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_NEG = 3 };
 
@@ -1013,6 +1014,155 @@ extern "C" int gpupoly_matrix_mul_batch(GpuMatrix *const *outs, const GpuMatrix 
         else
             hipLaunchKernelGGL(matmul_batch_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, L, ctx->logN);
         HIP_TRY(hipGetLastError());
+    }
+    return 0;
+    ABI_GUARD_END
+}
+
+// ---- a level of circuit gates in one call (extension) -------------------------------------------------
+// The reference evaluates a circuit level gate by gate (src/circuit/poly_circuit/eval.rs:269-345: Add, Sub, Mul,
+// Small/LargeScalarMul each turn into one ABI call per gate, from gate-parallel rayon threads).  On a small ring every
+// such call is a launch-latency-bound kernel.  gpupoly_batch takes the independent gates of a level: the products go out
+// through gpupoly_matrix_mul_batch (up to 64 per launch), the point-wise gates (add / sub / negate / product by a 1x1
+// ring element) up to 64 per launch through the kernel below, decompositions one by one through the tuned path.
+struct EwBatchItem {
+    void *out;
+    const void *a, *b;
+    uint64_t words;           // residues of the output
+    uint32_t words_per_poly;  // broadcast period of b for MUL_SCALAR
+    uint32_t op;              // OP_* ; bit 8: b is one polynomial broadcast over a
+};
+struct EwBatchArgs {
+    EwBatchItem item[kMulBatchMax];
+};
+
+template <typename W>
+__global__ void __launch_bounds__(256) elementwise_batch_kernel(EwBatchArgs args, const LimbConst *__restrict__ limbs, uint32_t L, uint32_t logN) {
+    const EwBatchItem it = args.item[blockIdx.y];
+    const uint32_t op = it.op & 0xffu;
+    const bool bcast = (it.op & 0x100u) != 0;
+    const W *a = static_cast<const W *>(it.a), *b = static_cast<const W *>(it.b);
+    W *out = static_cast<W *>(it.out);
+    for (size_t w = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < it.words; w += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const LimbConst lc = limbs[(w >> logN) % L];
+        const W q = static_cast<W>(lc.q);
+        const W av = a[w], bv = b[bcast ? w % it.words_per_poly : w];
+        W r;
+        if (op == OP_ADD) r = add_mod<W>(av, bv, q);
+        else if (op == OP_SUB) r = sub_mod<W>(av, bv, q);
+        else if (op == OP_NEG) r = bv ? static_cast<W>(q - bv) : static_cast<W>(0);
+        else r = mul_mod<W>(av, bv, q, lc.mu, lc.kbits);
+        out[w] = r;
+    }
+}
+
+extern "C" int gpupoly_batch(const GpuBatchOp *ops, size_t count, uint32_t base_bits) {
+    ABI_GUARD_BEGIN
+    if (count == 0) return 0;
+    if (!ops) return set_error("gpupoly_batch: null ops");
+    GpuContext *ctx = nullptr;
+    for (size_t i = 0; i < count; ++i) {
+        const GpuBatchOp &o = ops[i];
+        if (!o.out || !o.lhs) return set_error("gpupoly_batch: null matrix");
+        if (o.kind < GPUPOLY_OP_MUL || o.kind > GPUPOLY_OP_MUL_DECOMPOSE) return set_error("gpupoly_batch: unknown gate kind");
+        const bool unary = o.kind == GPUPOLY_OP_NEG || o.kind == GPUPOLY_OP_DECOMPOSE;
+        if (!unary && !o.rhs) return set_error("gpupoly_batch: null right operand");
+        if (!ctx) ctx = o.out->ctx;
+        if (o.out->ctx != ctx || o.lhs->ctx != ctx || (!unary && o.rhs->ctx != ctx)) return set_error("gpupoly_batch: context mismatch");
+        // the gates of a level are unordered: no output may be read or written by another gate
+        for (size_t j = 0; j < count; ++j)
+            if (j != i && (ops[j].out == o.out || ops[j].lhs == o.out || ops[j].rhs == o.out))
+                return set_error("gpupoly_batch: an output aliases another gate's operand");
+    }
+    if (ctx_activate(ctx)) return 1;
+    const uint32_t logN = ctx->logN;
+    // products: one batched call over the MUL gates (validated there)
+    {
+        std::vector<GpuMatrix *> outs;
+        std::vector<const GpuMatrix *> ls, rs;
+        for (size_t i = 0; i < count; ++i)
+            if (ops[i].kind == GPUPOLY_OP_MUL) {
+                outs.push_back(ops[i].out);
+                ls.push_back(ops[i].lhs);
+                rs.push_back(ops[i].rhs);
+            }
+        if (!outs.empty())
+            if (int rc = gpupoly_matrix_mul_batch(outs.data(), ls.data(), rs.data(), outs.size())) return rc;
+    }
+    // point-wise gates, grouped by level (the kernel takes one limb count per launch)
+    std::vector<size_t> ew;
+    for (size_t i = 0; i < count; ++i) {
+        const GpuBatchOp &o = ops[i];
+        if (o.kind == GPUPOLY_OP_ADD || o.kind == GPUPOLY_OP_SUB || o.kind == GPUPOLY_OP_NEG || o.kind == GPUPOLY_OP_MUL_SCALAR) {
+            const GpuMatrix *b = o.kind == GPUPOLY_OP_NEG ? o.lhs : o.rhs;
+            if (matrix_check_same_shape(o.out, o.lhs, "gpupoly_batch")) return 1;
+            if (o.kind == GPUPOLY_OP_MUL_SCALAR) {
+                if (b->level != o.lhs->level || b->rows != 1 || b->cols != 1) return set_error("gpupoly_batch: scalar must be 1x1 at the operand's level");
+                if (o.lhs->format != GPU_POLY_FORMAT_EVAL || b->format != GPU_POLY_FORMAT_EVAL)
+                    return set_error("gpupoly_batch: mul_scalar requires Eval format");
+            } else if (matrix_check_same_shape(o.lhs, b, "gpupoly_batch")) {
+                return 1;
+            }
+            if (matrix_words(o.out) > (size_t(1) << 24)) {  // fills the chip by itself: the 16-bytes-per-lane kernels
+                int rc = o.kind == GPUPOLY_OP_ADD   ? gpu_matrix_add(o.out, o.lhs, o.rhs)
+                         : o.kind == GPUPOLY_OP_SUB ? gpu_matrix_sub(o.out, o.lhs, o.rhs)
+                         : o.kind == GPUPOLY_OP_NEG ? gpupoly_matrix_neg(o.out, o.lhs)
+                                                    : gpu_matrix_mul_scalar(o.out, o.lhs, o.rhs);
+                if (rc) return rc;
+                continue;
+            }
+            ew.push_back(i);
+        }
+    }
+    std::vector<char> done(ew.size(), 0);
+    for (size_t first = 0; first < ew.size(); ++first) {
+        if (done[first]) continue;
+        const int level = ops[ew[first]].out->level;
+        EwBatchArgs args;
+        size_t live = 0, max_words = 0;
+        auto flush = [&]() -> int {
+            if (live == 0) return 0;
+            const dim3 grid(static_cast<unsigned>(std::min<size_t>((max_words + 255) / 256, 4096)), static_cast<unsigned>(live));
+            if (ctx->wide)
+                hipLaunchKernelGGL(elementwise_batch_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, static_cast<uint32_t>(level + 1), logN);
+            else
+                hipLaunchKernelGGL(elementwise_batch_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, static_cast<uint32_t>(level + 1), logN);
+            HIP_TRY(hipGetLastError());
+            live = 0;
+            max_words = 0;
+            return 0;
+        };
+        for (size_t e = first; e < ew.size(); ++e) {
+            const GpuBatchOp &o = ops[ew[e]];
+            if (done[e] || o.out->level != level) continue;
+            done[e] = 1;
+            const GpuMatrix *b = o.kind == GPUPOLY_OP_NEG ? o.lhs : o.rhs;
+            // format tags as the single-gate entry points set them
+            o.out->format = o.kind == GPUPOLY_OP_MUL_SCALAR ? GPU_POLY_FORMAT_EVAL : b->format;
+            const size_t words = matrix_words(o.out);
+            if (words == 0) continue;
+            EwBatchItem &it = args.item[live++];
+            it.out = o.out->data;
+            it.a = o.lhs->data;
+            it.b = b->data;
+            it.words = words;
+            it.words_per_poly = static_cast<uint32_t>(matrix_limbs(o.out) << logN);
+            it.op = (o.kind == GPUPOLY_OP_ADD ? OP_ADD : o.kind == GPUPOLY_OP_SUB ? OP_SUB : o.kind == GPUPOLY_OP_NEG ? OP_NEG : OP_MUL) |
+                    (o.kind == GPUPOLY_OP_MUL_SCALAR ? 0x100u : 0u);
+            max_words = std::max(max_words, words);
+            if (live == kMulBatchMax)
+                if (int rc = flush()) return rc;
+        }
+        if (int rc = flush()) return rc;
+    }
+    // decompositions: multi-kernel operations with their own tuned paths
+    for (size_t i = 0; i < count; ++i) {
+        const GpuBatchOp &o = ops[i];
+        if (o.kind == GPUPOLY_OP_DECOMPOSE) {
+            if (int rc = gpu_matrix_decompose_base(o.lhs, base_bits, o.out)) return rc;
+        } else if (o.kind == GPUPOLY_OP_MUL_DECOMPOSE) {
+            if (int rc = gpupoly_matrix_mul_decompose(o.out, o.lhs, o.rhs, base_bits)) return rc;
+        }
     }
     return 0;
     ABI_GUARD_END

@@ -696,6 +696,45 @@ class GpuDCRTPolyMatrix:
         check_status(st, "gpupoly_matrix_mul_batch")
         return outs
 
+    @staticmethod
+    def eval_gates(gates) -> list:
+        """One level of independent circuit gates through `gpupoly_batch` (src/circuit/poly_circuit/eval.rs:269-345
+        issues one ABI call per gate).  `gates` = [(kind, lhs, rhs_or_None), ...] with kind in {"mul", "add", "sub",
+        "mul_scalar", "neg", "decompose", "mul_decompose"}; returns the gate outputs in order."""
+        if not gates:
+            return []
+        kinds = {"mul": _ffi.GPUPOLY_OP_MUL, "add": _ffi.GPUPOLY_OP_ADD, "sub": _ffi.GPUPOLY_OP_SUB,
+                 "mul_scalar": _ffi.GPUPOLY_OP_MUL_SCALAR, "neg": _ffi.GPUPOLY_OP_NEG,
+                 "decompose": _ffi.GPUPOLY_OP_DECOMPOSE, "mul_decompose": _ffi.GPUPOLY_OP_MUL_DECOMPOSE}
+        params = gates[0][1].params
+        k = params.modulus_digits()
+        ops = (_ffi.GpuBatchOp * len(gates))()
+        outs, keep = [], []
+        for i, (kind, lhs, rhs) in enumerate(gates):
+            code = kinds[kind]
+            if kind in ("mul", "mul_scalar", "mul_decompose"):
+                lhs = lhs.ensure_eval()
+                if kind != "mul_decompose":
+                    rhs = rhs.ensure_eval()
+            elif kind in ("add", "sub"):
+                assert lhs.is_ntt == rhs.is_ntt, "add / sub gates need operands in one domain"
+            if kind == "mul":
+                out = GpuDCRTPolyMatrix(params, lhs.nrow, rhs.ncol, lhs.level, True)
+            elif kind == "decompose":
+                out = GpuDCRTPolyMatrix(params, lhs.nrow * k, lhs.ncol, lhs.level, True)
+            elif kind == "mul_decompose":
+                out = GpuDCRTPolyMatrix(params, lhs.nrow, rhs.ncol, lhs.level, True)
+            else:
+                out = GpuDCRTPolyMatrix(params, lhs.nrow, lhs.ncol, lhs.level, lhs.is_ntt)
+            keep.append((lhs, rhs))
+            ops[i].kind, ops[i].out, ops[i].lhs = code, out.raw, lhs.raw
+            ops[i].rhs = rhs.raw if rhs is not None else None
+            outs.append(out)
+        check_status(_ffi.lib().gpupoly_batch(ops, len(gates), params.base_bits()), "gpupoly_batch")
+        for (kind, lhs, rhs), out in zip(gates, outs):
+            out.is_ntt = True if kind in ("mul", "mul_scalar", "decompose", "mul_decompose") else (rhs if rhs is not None else lhs).is_ntt
+        return outs
+
     # ---- PolyMatrix trait defaults the GPU wrapper inherits (src/matrix/mod.rs:185-345) ------------------------
     def decompose_chunk(self, chunk_idx, chunk_count) -> "GpuDCRTPolyMatrix":
         assert chunk_count > 0, "decompose_chunk chunk_count must be > 0"

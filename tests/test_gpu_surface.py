@@ -476,3 +476,59 @@ def test_neg_extension_and_three_operand_add_sub(gpu, oracle, n, depth, bits):
         _ffi.check_status(_ffi.lib().gpupoly_matrix_neg(ga.raw, ga.raw), "gpupoly_matrix_neg")  # in place
         assert ga == neg
     assert not (gpu.GpuDCRTPolyMatrix.from_rns(p, a, True) == gpu.GpuDCRTPolyMatrix.from_rns(p, b, True))
+
+
+@pytest.mark.parametrize("n,depth,bits,base", [(256, 3, 51, 17), (1024, 2, 24, 12)])
+def test_gate_batch_all_kinds_against_the_oracle(gpu, oracle, n, depth, bits, base):
+    """gpupoly_batch: one level of independent gates - products, add / sub / negate, products by a ring element,
+    decompositions - in one ABI call (src/circuit/poly_circuit/eval.rs:269-345 issues one call per gate); every output
+    against the CPU restatement, including 70 point-wise gates (more than one launch's 64 descriptors), mixed shapes,
+    COEFF operands for add / sub, and a gate at a lower level."""
+    from mxx_amd import _ffi
+
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    M = gpu.GpuDCRTPolyMatrix
+    ev = lambda x: oracle.matrix_ntt(x, moduli)
+    rnd = lambda seed, r, c: ev(rand_matrix(oracle, seed, r, c, moduli, n))
+    gates, want = [], []
+    for i in range(70):
+        r, c = 1 + i % 3, 1 + (i // 3) % 4
+        a, b = rnd(1000 + 2 * i, r, c), rnd(1001 + 2 * i, r, c)
+        kind = ("add", "sub", "neg", "mul_scalar")[i % 4]
+        if kind == "mul_scalar":
+            s_ = rnd(1200 + i, 1, 1)
+            gates.append((kind, M.from_rns(p, a, True), M.from_rns(p, s_, True)))
+            want.append(oracle.pointwise("mul", a, np.broadcast_to(s_, a.shape).copy(), moduli))
+        elif kind == "neg":
+            gates.append((kind, M.from_rns(p, a, True), None))
+            want.append(oracle.pointwise("sub", np.zeros_like(a), a, moduli))
+        else:
+            gates.append((kind, M.from_rns(p, a, i % 8 < 4), M.from_rns(p, b, i % 8 < 4)))  # EVAL and COEFF pairs
+            want.append(oracle.pointwise(kind, a, b, moduli))
+    for i in range(5):
+        a, b = rnd(1400 + i, 2, 3 + i), rnd(1410 + i, 3 + i, 2)
+        gates.append(("mul", M.from_rns(p, a, True), M.from_rns(p, b, True)))
+        want.append(oracle.matmul(a, b, moduli))
+    src = rand_matrix(oracle, 1500, 2, 2, moduli, n)
+    gates.append(("decompose", M.from_rns(p, src, False), None))
+    want.append(ev(oracle.decompose(src, moduli, base)))
+    k = p.modulus_digits()
+    sm, bm = rnd(1501, 1, 2 * k), rand_matrix(oracle, 1502, 2, 3, moduli, n)
+    gates.append(("mul_decompose", M.from_rns(p, sm, True), M.from_rns(p, ev(bm), True)))
+    want.append(oracle.matmul(sm, ev(oracle.decompose(bm, moduli, base)), moduli))
+    # a gate at a lower level rides in the same call (its own launch: one limb count per launch)
+    lo_a, lo_b = rnd(1600, 1, 2)[:, :, : depth - 1], rnd(1601, 1, 2)[:, :, : depth - 1]
+    gates.append(("add", M.from_rns(p, np.ascontiguousarray(lo_a), True), M.from_rns(p, np.ascontiguousarray(lo_b), True)))
+    want.append(oracle.pointwise("add", np.ascontiguousarray(lo_a), np.ascontiguousarray(lo_b), moduli[: depth - 1]))
+    outs = M.eval_gates(gates)
+    assert len(outs) == len(want)
+    for i, (o, w, g) in enumerate(zip(outs, want, gates)):
+        assert np.array_equal(o.to_rns(), w), (i, g[0])
+        if g[0] in ("add", "sub"):
+            assert o.is_ntt == g[1].is_ntt
+    # aliasing between gates is refused: the gates of a level are unordered
+    ops = (_ffi.GpuBatchOp * 2)()
+    ops[0].kind, ops[0].out, ops[0].lhs, ops[0].rhs = _ffi.GPUPOLY_OP_ADD, outs[0].raw, outs[1].raw, outs[1].raw
+    ops[1].kind, ops[1].out, ops[1].lhs, ops[1].rhs = _ffi.GPUPOLY_OP_ADD, outs[1].raw, outs[1].raw, outs[1].raw
+    assert _ffi.lib().gpupoly_batch(ops, 2, base) != 0 and "aliases" in _ffi.last_error_string()

@@ -1,5 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_surface.py -x -q -k "mul_scalar_intt" > gpurun_out/r03b_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_surface.py -x -q -k "gate_batch or mul_batch" > gpurun_out/r03b_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/r03b_tests.log
-tail -15 gpurun_out/r03b_tests.log
+tail -25 gpurun_out/r03b_tests.log
