@@ -328,6 +328,44 @@ class M1(Workload):
         return statistics.fmean(mul_ms), statistics.fmean(inv_ms)
 
 
+def large_batch_kernels(mx, device, polys=4096, reps=6):
+    """The M1 kernels on a batch the Infinity Cache cannot hold (4096 polys x 4 limbs x 2^14 x 4 B = 1.07 GB; M1's own
+    268 MB batch about equals the 256 MiB cache, which flatters its GB/s): forward / inverse transform, the fused
+    product + inverse and the stand-alone mod-mul, hipEvent time per launch."""
+    from mxx_amd import _ffi
+
+    lib = _ffi.lib()
+    p = mx.GpuDCRTPolyParams(N_RING, mx.gen_crt_basis(N_RING, 4, 24), 12, gpu_ids=[device])
+    ctx = p.ctx()
+    x = uniform_matrix(mx, p, polys, 1, 21)
+    w = uniform_matrix(mx, p, 1, 1, 22)
+    algo = 2.0 * N_RING * 4 * polys * 4
+    calls = {
+        "ntt_inverse": lambda: _ffi.check_status(lib.gpu_matrix_intt_all(x.raw), "intt"),
+        "ntt_forward": lambda: _ffi.check_status(lib.gpu_matrix_ntt_all(x.raw), "ntt"),
+        "mod_mul": lambda: _ffi.check_status(lib.gpu_matrix_mul_scalar(x.raw, x.raw, w.raw), "mul_scalar"),
+        "mul_intt_fused": lambda: _ffi.check_status(lib.gpupoly_matrix_mul_scalar_intt(x.raw, x.raw, w.raw), "mul_scalar_intt"),
+    }
+    order = ["ntt_inverse", "ntt_forward", "mod_mul", "mul_intt_fused"]  # formats alternate EVAL -> COEFF -> EVAL -> EVAL -> COEFF
+    base, ms = 50000, {k: [] for k in order}
+    for rep in range(reps + 1):  # the first repetition creates the hipEvents and warms the kernels
+        for j, k in enumerate(order):
+            ctx.timer_mark(base + 2 * j)
+            calls[k]()
+            ctx.timer_mark(base + 2 * j + 1)
+        if rep:
+            for j, k in enumerate(order):
+                ms[k].append(ctx.timer_elapsed(base + 2 * j, base + 2 * j + 1))
+        _ffi.check_status(lib.gpu_matrix_ntt_all(x.raw), "ntt")  # back to EVAL for the next repetition
+    out = {"batch": f"{polys} polys x 4 limbs x 2^14 (u32): {algo / 2e9:.2f} GB per operand, beyond the 256 MiB Infinity Cache"}
+    for k in order:
+        t = statistics.median(ms[k])
+        gbs = algo / (t * 1e-3) / 1e9
+        out[k] = {"us": round(t * 1e3, 1), "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                  "ns_per_vector": round(t * 1e6 / (polys * 4), 2)}
+    return out
+
+
 class MatMul(Workload):
     def setup(self):
         mx, p, d = self.mx, self.params, self.d
@@ -545,11 +583,15 @@ class M4(Workload):
         self.sharding = "independent chains per rank, no collective"
 
     def step(self, i, mark):
+        from mxx_amd import _ffi
+
         if mark:
             self.mark(i, 0)
+        n0 = _ffi.lib().gpupoly_launch_count()
         self.k = self.sampler.preimage(self.params, self.td0, self.a0, self.target)
         self.c1 = self.c0 * self.k
         self.md = self.bmat.mul_decompose(self.mmat)
+        self.launches_per_step = _ffi.lib().gpupoly_launch_count() - n0
         if mark:
             self.mark(i, 1)
 
@@ -678,6 +720,7 @@ def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
                    "limb_bits": 24 if wl.word == 4 else 51, "units_per_step": wl.units, "sharding": wl.sharding},
         "repeats": res["repeats"],
         "roofline": roofline_of(wl, res["kernel_ms"]),
+        **({"kernel_launches_per_step": int(wl.launches_per_step)} if hasattr(wl, "launches_per_step") else {}),
     }
 
 
@@ -868,11 +911,28 @@ def main():
             pre.pop(key, None)
         pre.pop("roofline", None)
         pre["call_ms_hipevents"] = round(pre_res["kernel_ms"][0], 4)
+        if d.world == 1:
+            # one rank's share at N = 8 (7 of the 50 columns): what column sharding can reach before any exchange - a
+            # call of 7 columns is not 7/50 of a call of 50 (fixed costs, partly filled sampler waves)
+            t7 = uniform_matrix(mx, pre_wl.params, 1, 7, 9, total_cols=50, col_start=0)
+            call = lambda: pre_wl.sampler.preimage(pre_wl.params, pre_wl.td, pre_wl.pub, t7)
+            for _ in range(3):
+                call()
+            times = []
+            for _ in range(5):
+                pre_wl.ctx.timer_start()
+                call()
+                times.append(pre_wl.ctx.timer_stop())
+            ms7 = statistics.median(times)
+            pre["shard_of_8"] = {"columns": 7, "call_ms": round(ms7, 4), "linear_share_ms": round(pre_res["kernel_ms"][0] * 7 / 50, 4),
+                                 "predicted_strong_scaling_efficiency_at_8": round(pre_res["kernel_ms"][0] / (8 * ms7), 3)}
         line["preimage"] = pre
         del pre_wl
         m1, m1_res = run("m1", steps, warmup, 0)
         line["kernels"] = kernels_block(m1, m1_res)
         del m1
+        if d.world == 1:
+            line["kernels"]["large_batch"] = large_batch_kernels(mx, device)
         if d.rank == 0 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline("m2a", args.cpu_seconds)
             line["preimage"]["cpu_baseline"] = cpu_baseline("m3a", args.cpu_seconds)
@@ -882,6 +942,9 @@ def main():
         line = block_json(wl, res, d, args, steps, warmup)
         if args.workload == "m1":
             line["kernels"] = kernels_block(wl, res)
+            if d.world == 1:
+                del wl
+                line["kernels"]["large_batch"] = large_batch_kernels(mx, device)
         if d.rank == 0 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
     if d.rank == 0:

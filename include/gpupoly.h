@@ -249,6 +249,9 @@ const char *gpupoly_comm_backend(const GpuComm *comm); /* "rccl" or "peer" */
  * the call.  One row and equal shards gather straight into full[s]; other shapes go through a padded staging block
  * of the context's allocator.  Call it from one host thread (after the per-device workers have joined).           */
 int gpupoly_matrix_all_gather_columns(GpuComm *comm, const GpuMatrix *const *local_blocks, GpuMatrix *const *full);
+/* kernel launches issued by the library since it was loaded (every context; copies / memsets not counted): bench.py
+ * reports launches per step for the launch-bound small-ring chain                                              */
+uint64_t gpupoly_launch_count(void);
 const char *gpupoly_version(void);
 /* MXX_HIP_* switches are read once, at gpu_context_create; this re-reads them for every live
  * context of the process (tests flip them between calls).                      */

@@ -130,6 +130,7 @@ SIGNATURES = {
     "gpupoly_comm_size": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_comm_backend": (C.c_char_p, [_vp]),
     "gpupoly_matrix_all_gather_columns": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "gpupoly_launch_count": (C.c_uint64, []),
     "gpupoly_version": (C.c_char_p, []),
     "gpupoly_reload_env": (C.c_int, []),
 }

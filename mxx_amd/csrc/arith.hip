@@ -441,7 +441,7 @@ static int launch_matmul_lds_u32(GpuMatrix *out, const GpuMatrix *lhs, const Gpu
     if (blocks > 0x7fffffffull) return set_error("gpu_matrix_mul: matrix too large");
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
     ctx->last_kernel = "matmul_lds_kernel_u32 (64 slots x 16x16 tile, operands staged through registers into LDS)";
-    hipLaunchKernelGGL(matmul_lds_kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
+    MXX_LAUNCH(matmul_lds_kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
                        col_tiles, slot_chunks, remap);
@@ -471,11 +471,11 @@ static int launch_matmul_cfg(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatr
     // (a smaller B is often re-used from cache by the next product - the hint made repeated products on a 134 MB operand
     // 40 % slower)
     if (nt)
-        hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, true>), grid, dim3(threads), 0, ctx->stream,
+        MXX_LAUNCH((matmul_kernel<W, TR, TC, SV, PF, true>), grid, dim3(threads), 0, ctx->stream,
                            static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
                            static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
     else
-        hipLaunchKernelGGL((matmul_kernel<W, TR, TC, SV, PF, false>), grid, dim3(threads), 0, ctx->stream,
+        MXX_LAUNCH((matmul_kernel<W, TR, TC, SV, PF, false>), grid, dim3(threads), 0, ctx->stream,
                            static_cast<W *>(out->data), static_cast<const W *>(lhs->data),
                            static_cast<const W *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, col_tiles);
     HIP_TRY(hipGetLastError());
@@ -583,12 +583,12 @@ static int launch_elementwise_typed(GpuMatrix *out, const GpuMatrix *a, const Gp
     if (ctx->N >= VNATIVE) {
         const size_t vecs = words / VNATIVE;
         unsigned blocks = static_cast<unsigned>(std::min<size_t>((vecs + 255) / 256, 16384));
-        hipLaunchKernelGGL((elementwise_kernel<W, OP, BCAST, VNATIVE>), dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH((elementwise_kernel<W, OP, BCAST, VNATIVE>), dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<W *>(out->data), static_cast<const W *>(a->data),
                            static_cast<const W *>(b->data), ctx->d_limbs, L, ctx->logN, wpp, vecs);
     } else {
         unsigned blocks = static_cast<unsigned>(std::min<size_t>((words + 255) / 256, 16384));
-        hipLaunchKernelGGL((elementwise_kernel<W, OP, BCAST, 1>), dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH((elementwise_kernel<W, OP, BCAST, 1>), dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<W *>(out->data), static_cast<const W *>(a->data),
                            static_cast<const W *>(b->data), ctx->d_limbs, L, ctx->logN, wpp, words);
     }
@@ -702,12 +702,12 @@ static int launch_tensor_typed(GpuMatrix *out, const GpuMatrix *a, const GpuMatr
     if (gz > 65535) return set_error("gpupoly_matrix_tensor: matrix too large");
     if (ctx->N >= VNATIVE) {
         const dim3 grid(static_cast<unsigned>(std::min<size_t>((wpp / VNATIVE + 255) / 256, 64)), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
-        hipLaunchKernelGGL((tensor_kernel<W, VNATIVE>), grid, dim3(256), 0, ctx->stream, static_cast<W *>(out->data),
+        MXX_LAUNCH((tensor_kernel<W, VNATIVE>), grid, dim3(256), 0, ctx->stream, static_cast<W *>(out->data),
                            static_cast<const W *>(a->data), static_cast<const W *>(b->data), ctx->d_limbs, ctx->logN, wpp,
                            a->cols, b->rows, b->cols, polys);
     } else {
         const dim3 grid(static_cast<unsigned>(std::min<size_t>((wpp + 255) / 256, 64)), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
-        hipLaunchKernelGGL((tensor_kernel<W, 1>), grid, dim3(256), 0, ctx->stream, static_cast<W *>(out->data),
+        MXX_LAUNCH((tensor_kernel<W, 1>), grid, dim3(256), 0, ctx->stream, static_cast<W *>(out->data),
                            static_cast<const W *>(a->data), static_cast<const W *>(b->data), ctx->d_limbs, ctx->logN, wpp,
                            a->cols, b->rows, b->cols, polys);
     }
@@ -1010,9 +1010,9 @@ extern "C" int gpupoly_matrix_mul_batch(GpuMatrix *const *outs, const GpuMatrix 
         if (live == 0) continue;
         const dim3 grid(static_cast<unsigned>((max_total + 255) / 256), static_cast<unsigned>(live));
         if (ctx->wide)
-            hipLaunchKernelGGL(matmul_batch_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, L, ctx->logN);
+            MXX_LAUNCH(matmul_batch_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, L, ctx->logN);
         else
-            hipLaunchKernelGGL(matmul_batch_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, L, ctx->logN);
+            MXX_LAUNCH(matmul_batch_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, L, ctx->logN);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -1124,9 +1124,9 @@ extern "C" int gpupoly_batch(const GpuBatchOp *ops, size_t count, uint32_t base_
             if (live == 0) return 0;
             const dim3 grid(static_cast<unsigned>(std::min<size_t>((max_words + 255) / 256, 4096)), static_cast<unsigned>(live));
             if (ctx->wide)
-                hipLaunchKernelGGL(elementwise_batch_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, static_cast<uint32_t>(level + 1), logN);
+                MXX_LAUNCH(elementwise_batch_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, static_cast<uint32_t>(level + 1), logN);
             else
-                hipLaunchKernelGGL(elementwise_batch_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, static_cast<uint32_t>(level + 1), logN);
+                MXX_LAUNCH(elementwise_batch_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, args, ctx->d_limbs, static_cast<uint32_t>(level + 1), logN);
             HIP_TRY(hipGetLastError());
             live = 0;
             max_words = 0;
@@ -1184,23 +1184,23 @@ extern "C" int gpu_matrix_equal(const GpuMatrix *lhs, const GpuMatrix *rhs, int 
     }
     GpuContext *ctx = lhs->ctx;
     if (ctx_activate(ctx)) return 1;
-    void *flag = nullptr;
-    if (ctx_alloc(ctx, sizeof(int), &flag)) return 1;
+    CtxBlock flag_block(ctx);
+    if (flag_block.alloc(sizeof(int))) return 1;
+    void *const flag = flag_block.ptr;
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
     unsigned blocks = static_cast<unsigned>(std::min<size_t>((words + 255) / 256, 8192));
     if (ctx->wide)
-        hipLaunchKernelGGL(equal_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(equal_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<const uint64_t *>(lhs->data), static_cast<const uint64_t *>(rhs->data), words,
                            static_cast<int *>(flag));
     else
-        hipLaunchKernelGGL(equal_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(equal_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<const uint32_t *>(lhs->data), static_cast<const uint32_t *>(rhs->data), words,
                            static_cast<int *>(flag));
     HIP_TRY(hipGetLastError());
     int diff = 0;
     HIP_TRY(hipMemcpyAsync(&diff, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx_free(ctx, flag);
     *out_equal = diff ? 0 : 1;
     return 0;
     ABI_GUARD_END

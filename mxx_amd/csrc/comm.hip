@@ -108,7 +108,7 @@ static int copy_rect(GpuComm *comm, size_t dst_rank, size_t src_rank, char *dst,
     if (vec_ok && direct && (!same || comm->copy_kernel)) {
         const size_t run_vec = run_bytes / 16;
         const unsigned gx = static_cast<unsigned>(std::min<size_t>((run_vec + 255) / 256, 1024));
-        hipLaunchKernelGGL(gather_rect_kernel, dim3(gx, static_cast<unsigned>(rows)), dim3(256), 0, dctx->stream,
+        MXX_LAUNCH(gather_rect_kernel, dim3(gx, static_cast<unsigned>(rows)), dim3(256), 0, dctx->stream,
                            reinterpret_cast<uint4 *>(dst), reinterpret_cast<const uint4 *>(src), dst_pitch / 16,
                            src_pitch / 16, run_vec);
         HIP_TRY(hipGetLastError());

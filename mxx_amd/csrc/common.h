@@ -136,6 +136,15 @@ __device__ __forceinline__ size_t item_index() {
 }
 #endif
 
+// every kernel launch of the library goes through this (bench.py prints launches per step for the launch-bound
+// small-ring chain: gpupoly_launch_count)
+extern std::atomic<uint64_t> g_kernel_launches;
+#define MXX_LAUNCH(...)                                             \
+    do {                                                            \
+        g_kernel_launches.fetch_add(1, std::memory_order_relaxed);  \
+        hipLaunchKernelGGL(__VA_ARGS__);                            \
+    } while (0)
+
 // ---- error plumbing ---------------------------------------------------------
 int set_error(const char *msg);
 int set_error(const std::string &msg);

@@ -111,11 +111,11 @@ static int fill_gadget_impl(GpuMatrix *out, uint32_t base_bits, bool small) {
     if (ctx_activate(ctx)) return 1;
     const dim3 blocks = item_grid(total, 256);
     if (ctx->wide)
-        hipLaunchKernelGGL(fill_gadget_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(fill_gadget_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(out->data), ctx->d_limbs, out->rows, out->cols, (uint32_t)L,
                            (uint32_t)ctx->N, dpt, k, base_bits, small ? 1 : 0);
     else
-        hipLaunchKernelGGL(fill_gadget_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(fill_gadget_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(out->data), ctx->d_limbs, out->rows, out->cols, (uint32_t)L,
                            (uint32_t)ctx->N, dpt, k, base_bits, small ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -143,16 +143,13 @@ static int decompose_impl(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *o
     if (ctx_activate(ctx)) return 1;
     // digits are taken from coefficient-domain residues: INTT a private copy if needed
     const void *coeff = src->data;
-    void *tmp = nullptr;
+    CtxBlock tmp_block(ctx);  // back to the cache at scope exit (stream-ordered behind its readers), error paths included
     if (src->format == GPU_POLY_FORMAT_EVAL) {
-        if (ctx_alloc(ctx, src->bytes, &tmp)) return 1;
-        HIP_TRY(hipMemcpyAsync(tmp, src->data, src->bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        int rc = launch_ntt(ctx, tmp, polys * L, static_cast<int>(L), true);
-        if (rc) {
-            ctx_free(ctx, tmp);
-            return rc;
-        }
-        coeff = tmp;
+        if (tmp_block.alloc(src->bytes)) return 1;
+        HIP_TRY(hipMemcpyAsync(tmp_block.ptr, src->data, src->bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        int rc = launch_ntt(ctx, tmp_block.ptr, polys * L, static_cast<int>(L), true);
+        if (rc) return rc;
+        coeff = tmp_block.ptr;
     }
     const uint32_t towers = small ? 1u : static_cast<uint32_t>(L);
     if (requested == GPU_POLY_FORMAT_EVAL) {
@@ -164,7 +161,6 @@ static int decompose_impl(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *o
                                                           matrix_polys(out) * L, static_cast<uint32_t>(L), (uint32_t)src->cols,
                                                           towers, dpt, base_bits, k);
         if (frc >= 0) {
-            if (tmp) ctx_free(ctx, tmp);
             if (frc == 0) out->format = GPU_POLY_FORMAT_EVAL;
             return frc;
         }
@@ -172,15 +168,14 @@ static int decompose_impl(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *o
     const size_t total = polys * towers * static_cast<size_t>(ctx->N);
     const dim3 blocks = item_grid(total, 256);
     if (ctx->wide)
-        hipLaunchKernelGGL(decompose_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(decompose_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(out->data), static_cast<const uint64_t *>(coeff), ctx->d_limbs, polys,
                            (uint32_t)src->cols, (uint32_t)L, (uint32_t)ctx->N, towers, dpt, base_bits, k);
     else
-        hipLaunchKernelGGL(decompose_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(decompose_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(coeff), ctx->d_limbs, polys,
                            (uint32_t)src->cols, (uint32_t)L, (uint32_t)ctx->N, towers, dpt, base_bits, k);
     HIP_TRY(hipGetLastError());
-    if (tmp) ctx_free(ctx, tmp);
     out->format = GPU_POLY_FORMAT_COEFF;
     if (requested == GPU_POLY_FORMAT_EVAL) {
         // output honours the format it was created with (MatrixDecompose.cu:910-914,1318-1328)
@@ -239,11 +234,11 @@ extern "C" int gpu_matrix_fill_small_decomposed_identity_chunk(GpuMatrix *out, c
     const unsigned gx = static_cast<unsigned>(std::min<size_t>((wpp + 255) / 256, 64));
     dim3 grid(gx, static_cast<unsigned>(size));
     if (ctx->wide)
-        hipLaunchKernelGGL(identity_chunk_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(identity_chunk_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(out->data), static_cast<const uint64_t *>(scalar_by_digit->data),
                            size, chunk_idx, chunk_count, wpp);
     else
-        hipLaunchKernelGGL(identity_chunk_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(identity_chunk_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(scalar_by_digit->data),
                            size, chunk_idx, chunk_count, wpp);
     HIP_TRY(hipGetLastError());

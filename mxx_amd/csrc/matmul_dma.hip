@@ -417,7 +417,7 @@ int launch_matmul_dma32_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatri
     }
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
     ctx->last_kernel = "mmdma32::kernel_u32 (32 slots x 32x32 tile, 16 waves, global_load_lds four-stage ring)";
-    hipLaunchKernelGGL(mmdma32::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(1024), mmdma32::LDS_BYTES, ctx->stream,
+    MXX_LAUNCH(mmdma32::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(1024), mmdma32::LDS_BYTES, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
                        col_tiles, slot_chunks, remap, out->bytes >= (size_t(1) << 30) ? 1u : 0u);
@@ -446,7 +446,7 @@ int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix 
     }
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
     ctx->last_kernel = "mmdma::kernel_u32 (64 slots x 32x16 tile, 8 waves, global_load_lds three-stage ring)";
-    hipLaunchKernelGGL(mmdma::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(512), mmdma::LDS_BYTES, ctx->stream,
+    MXX_LAUNCH(mmdma::kernel_u32, dim3(static_cast<unsigned>(blocks)), dim3(512), mmdma::LDS_BYTES, ctx->stream,
                        static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,
                        col_tiles, slot_chunks, remap, out->bytes >= (size_t(1) << 30) ? 1u : 0u);

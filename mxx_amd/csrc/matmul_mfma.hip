@@ -245,7 +245,7 @@ int launch_matmul_mfma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix
     const uint32_t remap = (groups % 8 == 0) ? 1u : 0u;
     ctx->last_kernel = "mmfma::kernel_u32 (16 slots x 32x32 tile, 9 v_mfma_i32_32x32x32_i8 per 32-deep chunk on balanced int8 digits)";
 #define MMFMA_LAUNCH(M)                                                                                                   \
-    hipLaunchKernelGGL(mmfma::kernel_u32<M>, dim3(static_cast<unsigned>(blocks)), dim3(mmfma::THREADS), mmfma::LDS_BYTES, \
+    MXX_LAUNCH(mmfma::kernel_u32<M>, dim3(static_cast<unsigned>(blocks)), dim3(mmfma::THREADS), mmfma::LDS_BYTES, \
                        ctx->stream, static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(lhs->data),          \
                        static_cast<const uint32_t *>(rhs->data), ctx->d_limbs, rows, inner, cols, L, N, row_tiles,        \
                        col_tiles, slot_chunks, remap)

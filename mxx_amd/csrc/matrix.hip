@@ -119,10 +119,10 @@ int launch_scatter_i64(GpuMatrix *out, const int64_t *vals) {
     const dim3 blocks = item_grid(total, 256);
     uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
     if (ctx->wide)
-        hipLaunchKernelGGL(scatter_i64_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(scatter_i64_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(out->data), vals, ctx->d_limbs, polys, L, (uint32_t)ctx->N);
     else
-        hipLaunchKernelGGL(scatter_i64_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(scatter_i64_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(out->data), vals, ctx->d_limbs, polys, L, (uint32_t)ctx->N);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -179,12 +179,12 @@ int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size
         size_t rr = std::min(rows_per_launch, rows - r0);
         dim3 grid(gx, static_cast<unsigned>(rr * cols));
         if (ctx->wide)
-            hipLaunchKernelGGL((block_rect_kernel<uint64_t, true>), grid, dim3(256), 0, ctx->stream,
+            MXX_LAUNCH((block_rect_kernel<uint64_t, true>), grid, dim3(256), 0, ctx->stream,
                                static_cast<uint64_t *>(out->data), static_cast<const uint64_t *>(src->data),
                                ctx->d_limbs, out->cols, src->cols, dst_row + r0, dst_col, src_row + r0, src_col, cols,
                                wpp, (uint32_t)ctx->N);
         else
-            hipLaunchKernelGGL((block_rect_kernel<uint32_t, true>), grid, dim3(256), 0, ctx->stream,
+            MXX_LAUNCH((block_rect_kernel<uint32_t, true>), grid, dim3(256), 0, ctx->stream,
                                static_cast<uint32_t *>(out->data), static_cast<const uint32_t *>(src->data),
                                ctx->d_limbs, out->cols, src->cols, dst_row + r0, dst_col, src_row + r0, src_col, cols,
                                wpp, (uint32_t)ctx->N);
@@ -286,7 +286,7 @@ extern "C" int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src) {
     const unsigned gx = static_cast<unsigned>(std::min<size_t>((vec_per_poly + 255) / 256, 64));
     const size_t gy = std::min<size_t>(polys, 65535), gz = (polys + gy - 1) / gy;
     if (gz > 65535) return set_error("gpupoly_matrix_transpose: matrix too large");
-    hipLaunchKernelGGL(transpose_kernel, dim3(gx, static_cast<unsigned>(gy), static_cast<unsigned>(gz)), dim3(256), 0, ctx->stream,
+    MXX_LAUNCH(transpose_kernel, dim3(gx, static_cast<unsigned>(gy), static_cast<unsigned>(gz)), dim3(256), 0, ctx->stream,
                        static_cast<uint4 *>(out->data), static_cast<const uint4 *>(src->data), src->rows, src->cols, vec_per_poly);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -336,10 +336,10 @@ extern "C" int gpupoly_matrix_fill_identity(GpuMatrix *out, const GpuMatrix *sca
     const size_t words = matrix_limbs(out) * static_cast<size_t>(ctx->N);
     const dim3 grid(static_cast<unsigned>(std::min<size_t>((words + 255) / 256, 256)), static_cast<unsigned>(out->rows));
     if (ctx->wide)
-        hipLaunchKernelGGL(fill_diagonal_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, static_cast<uint64_t *>(out->data),
+        MXX_LAUNCH(fill_diagonal_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, static_cast<uint64_t *>(out->data),
                            scalar ? static_cast<const uint64_t *>(scalar->data) : nullptr, out->rows, words);
     else
-        hipLaunchKernelGGL(fill_diagonal_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, static_cast<uint32_t *>(out->data),
+        MXX_LAUNCH(fill_diagonal_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, static_cast<uint32_t *>(out->data),
                            scalar ? static_cast<const uint32_t *>(scalar->data) : nullptr, out->rows, words);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -483,11 +483,11 @@ extern "C" int gpu_matrix_load_rns_batch(GpuMatrix *mat, const uint8_t *bytes, s
         size_t total = pc * wpp;
         unsigned blocks = grid_for(total, 256);
         if (ctx->wide)
-            hipLaunchKernelGGL(unpack_rns_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+            MXX_LAUNCH(unpack_rns_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                                static_cast<const uint64_t *>(stage), static_cast<uint64_t *>(mat->data) + p0 * wpp,
                                wpp, src_wpp, total);
         else
-            hipLaunchKernelGGL(unpack_rns_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+            MXX_LAUNCH(unpack_rns_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                                static_cast<const uint64_t *>(stage), static_cast<uint32_t *>(mat->data) + p0 * wpp,
                                wpp, src_wpp, total);
         HIP_TRY(hipGetLastError());
@@ -525,11 +525,11 @@ extern "C" int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_o
         size_t total = pc * wpp;
         unsigned blocks = grid_for(total, 256);
         if (ctx->wide)
-            hipLaunchKernelGGL(pack_rns_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+            MXX_LAUNCH(pack_rns_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                                static_cast<const uint64_t *>(mat->data) + p0 * wpp, static_cast<uint64_t *>(stage), wpp,
                                dst_wpp, total);
         else
-            hipLaunchKernelGGL(pack_rns_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+            MXX_LAUNCH(pack_rns_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                                static_cast<const uint32_t *>(mat->data) + p0 * wpp, static_cast<uint64_t *>(stage), wpp,
                                dst_wpp, total);
         HIP_TRY(hipGetLastError());
@@ -561,11 +561,11 @@ extern "C" int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t
     if (words_per_poly != L) HIP_TRY(hipMemsetAsync(stage, 0, bytes, ctx->stream));
     const dim3 blocks = item_grid(polys * L, 256);
     if (ctx->wide)
-        hipLaunchKernelGGL(const_coeff_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(const_coeff_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<const uint64_t *>(mat->data), static_cast<uint64_t *>(stage), polys, L,
                            (size_t)ctx->N, words_per_poly);
     else
-        hipLaunchKernelGGL(const_coeff_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(const_coeff_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<const uint32_t *>(mat->data), static_cast<uint64_t *>(stage), polys, L,
                            (size_t)ctx->N, words_per_poly);
     HIP_TRY(hipGetLastError());

@@ -127,7 +127,7 @@ static int launch_generic(GpuContext *ctx, W *data, size_t vectors, uint32_t L) 
     unsigned threads = static_cast<unsigned>(N / 2);
     if (threads < 64) threads = 64;
     if (threads > 512) threads = 512;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(vectors)), dim3(threads), lds, ctx->stream, data,
+    MXX_LAUNCH(kern, dim3(static_cast<unsigned>(vectors)), dim3(threads), lds, ctx->stream, data,
                        static_cast<const W *>(INV ? ctx->d_tw_inv : ctx->d_tw_fwd),
                        static_cast<const W *>(INV ? ctx->d_tw_inv_sh : ctx->d_tw_fwd_sh), ctx->d_limbs, L, logN);
     HIP_TRY(hipGetLastError());
@@ -145,17 +145,17 @@ static int launch_global(GpuContext *ctx, W *data, size_t vectors, uint32_t L) {
     if (!INV) {
         uint32_t logt = logN - 1;
         for (uint32_t m = 1; m < (1u << logN); m <<= 1, --logt) {
-            hipLaunchKernelGGL((ntt_stage_global_kernel<W, false>), blocks, dim3(256), 0, ctx->stream, data, tw,
+            MXX_LAUNCH((ntt_stage_global_kernel<W, false>), blocks, dim3(256), 0, ctx->stream, data, tw,
                                tws, ctx->d_limbs, L, logN, m, logt, vectors);
         }
     } else {
         uint32_t logt = 0;
         for (uint32_t m = 1u << (logN - 1); m >= 1; m >>= 1, ++logt) {
-            hipLaunchKernelGGL((ntt_stage_global_kernel<W, true>), blocks, dim3(256), 0, ctx->stream, data, tw,
+            MXX_LAUNCH((ntt_stage_global_kernel<W, true>), blocks, dim3(256), 0, ctx->stream, data, tw,
                                tws, ctx->d_limbs, L, logN, m, logt, vectors);
         }
         const size_t words = vectors << logN;
-        hipLaunchKernelGGL(ntt_scale_global_kernel<W>, item_grid(words, 256), dim3(256), 0,
+        MXX_LAUNCH(ntt_scale_global_kernel<W>, item_grid(words, 256), dim3(256), 0,
                            ctx->stream, data, ctx->d_limbs, L, logN, words);
     }
     HIP_TRY(hipGetLastError());

@@ -44,10 +44,10 @@ int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff,
 #define MXX_DIGITS(RED, TGT)                                                                                                     \
     do {                                                                                                                         \
         if (nts)                                                                                                                 \
-            hipLaunchKernelGGL((ntt14::fwd_digits_kernel<W, RED, TGT, true>), grid, block, lds, ctx->stream, out, coeff, tw,      \
+            MXX_LAUNCH((ntt14::fwd_digits_kernel<W, RED, TGT, true>), grid, block, lds, ctx->stream, out, coeff, tw,      \
                                ctx->d_limbs, L, src_cols, towers, dpt, base_bits, k32);                                           \
         else                                                                                                                     \
-            hipLaunchKernelGGL((ntt14::fwd_digits_kernel<W, RED, TGT, false>), grid, block, lds, ctx->stream, out, coeff, tw,     \
+            MXX_LAUNCH((ntt14::fwd_digits_kernel<W, RED, TGT, false>), grid, block, lds, ctx->stream, out, coeff, tw,     \
                                ctx->d_limbs, L, src_cols, towers, dpt, base_bits, k32);                                           \
     } while (0)
     if (reduce) {

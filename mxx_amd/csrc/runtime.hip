@@ -31,6 +31,9 @@ int set_error(hipError_t err, const char *what) {
 
 extern "C" const char *gpu_last_error(void) { return g_last_error.c_str(); }
 extern "C" int gpu_set_last_error(const char *msg) { return set_error(msg); }
+std::atomic<uint64_t> g_kernel_launches{0};
+// kernel launches issued by this library since it was loaded (all contexts; copies and memsets not included)
+extern "C" uint64_t gpupoly_launch_count(void) { return g_kernel_launches.load(std::memory_order_relaxed); }
 extern "C" const char *gpupoly_version(void) { return "gpupoly-mi355x 0.1 (gfx950)"; }
 
 // ---- roctx (tracing) ---------------------------------------------------------------

@@ -210,7 +210,7 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
-        hipLaunchKernelGGL(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
+        MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
                            static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane);
         const hipError_t err = hipGetLastError();
         const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
@@ -225,12 +225,12 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         if (keys.alloc(sizeof(ChaChaKey) * nkeys)) return 1;
         ChaChaKey *d_keys = static_cast<ChaChaKey *>(keys.ptr);
         const uint64_t tag = uniform ? kTagUniform : (dist == GPU_MATRIX_DIST_BIT ? kTagBit : kTagTernary);
-        hipLaunchKernelGGL(derive_subkeys_kernel, dim3(1), dim3(64), 0, ctx->stream, d_keys, seed, tag, nkeys, uniform ? 1u : 0u);
+        MXX_LAUNCH(derive_subkeys_kernel, dim3(1), dim3(64), 0, ctx->stream, d_keys, seed, tag, nkeys, uniform ? 1u : 0u);
         HIP_TRY(hipGetLastError());
         const size_t threads = polys * (uniform ? L : 1u) * groups;
         const dim3 blocks = item_grid(threads, 256);
 #define MXX_SAMPLE(KERNEL, WORD, ...)                                                                                     \
-    hipLaunchKernelGGL(KERNEL<WORD>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<WORD *>(out->data), ctx->d_limbs, \
+    MXX_LAUNCH(KERNEL<WORD>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<WORD *>(out->data), ctx->d_limbs, \
                        d_keys, polys, out->cols, full_ncol, col_offset, L, N, groups, ##__VA_ARGS__)
         if (uniform) {
             if (ctx->wide) MXX_SAMPLE(sample_uniform_kernel, uint64_t);

@@ -304,9 +304,9 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned int), ctx->stream));
 #define SERDE_LAUNCH(KERNEL, WT, ...)                                                                                  \
     do {                                                                                                               \
-        if (sc.limbs <= 8) hipLaunchKernelGGL((KERNEL<WT, 8>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);         \
-        else if (sc.limbs <= 16) hipLaunchKernelGGL((KERNEL<WT, 16>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);  \
-        else hipLaunchKernelGGL((KERNEL<WT, 64>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);                      \
+        if (sc.limbs <= 8) MXX_LAUNCH((KERNEL<WT, 8>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);         \
+        else if (sc.limbs <= 16) MXX_LAUNCH((KERNEL<WT, 16>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);  \
+        else MXX_LAUNCH((KERNEL<WT, 64>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);                      \
     } while (0)
     if (ctx->wide)
         SERDE_LAUNCH(compact_maxbits_kernel, uint64_t, static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner,
@@ -378,11 +378,11 @@ extern "C" int gpu_matrix_load_compact_bytes(GpuMatrix *mat, const uint8_t *payl
     void *const d_payload = payload_block.ptr;
     const dim3 blocks = item_grid(coeffs, 256);
     if (ctx->wide)
-        hipLaunchKernelGGL(compact_unpack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(compact_unpack_kernel<uint64_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(mat->data), static_cast<const uint8_t *>(d_payload), polys, N, sc,
                            ctx->d_limbs, static_cast<uint32_t>(max_coeff_bits));
     else
-        hipLaunchKernelGGL(compact_unpack_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
+        MXX_LAUNCH(compact_unpack_kernel<uint32_t>, blocks, dim3(256), 0, ctx->stream,
                            static_cast<uint32_t *>(mat->data), static_cast<const uint8_t *>(d_payload), polys, N, sc,
                            ctx->d_limbs, static_cast<uint32_t>(max_coeff_bits));
     HIP_TRY(hipGetLastError());

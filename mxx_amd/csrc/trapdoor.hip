@@ -392,22 +392,22 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
     }
     double *a_words = static_cast<double *>(a_buf);
     uint64_t *left_words = static_cast<uint64_t *>(a_buf) + total * dpt;
-    hipLaunchKernelGGL(gadget_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream,
+    MXX_LAUNCH(gadget_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream,
                        static_cast<ChaChaKey *>(keys), N, seed);
-    hipLaunchKernelGGL(gq_tower_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<GqTower *>(towers), ctx->d_limbs,
+    MXX_LAUNCH(gq_tower_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<GqTower *>(towers), ctx->d_limbs,
                        L, dpt, base_bits, c);
-    hipLaunchKernelGGL((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
+    MXX_LAUNCH((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
                        ctx->stream, a_words, left_words, src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys), total, L,
                        ctx->logN, dpt, base_bits, c);
     const uint32_t per_lane =
         sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device, ctx->env.sampler_per_lane);
     const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
-    hipLaunchKernelGGL((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
+    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
                        static_cast<int64_t *>(stage), src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys),
                        static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
                        base_bits, c, karney_divisor(sigma), per_lane);
-    hipLaunchKernelGGL(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
+    MXX_LAUNCH(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
                        ctx->stream, out, static_cast<const int64_t *>(stage), ctx->d_limbs, total, src_cols, L, ctx->logN,
                        dpt, static_cast<uint32_t>(k));
     const hipError_t err = hipGetLastError();
@@ -430,7 +430,7 @@ static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys
     const dim3 blocks = item_grid(total, 128);
     const uint32_t N = static_cast<uint32_t>(ctx->N);
 #define LAUNCH_GS(MAXD)                                                                                        \
-    hipLaunchKernelGGL((gauss_samp_gq_kernel<W, MAXD>), dim3(blocks), dim3(128), 0, ctx->stream, out, src,      \
+    MXX_LAUNCH((gauss_samp_gq_kernel<W, MAXD>), dim3(blocks), dim3(128), 0, ctx->stream, out, src,      \
                        ctx->d_limbs, polys, src_cols, L, N, dpt, base_bits, c, k, seed)
     if (dpt <= 2) LAUNCH_GS(2);
     else if (dpt <= 4) LAUNCH_GS(4);
@@ -731,16 +731,16 @@ extern "C" int gpu_matrix_create_p1_covariance_cache(const GpuMatrix *a_mat, con
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(a_mat));
     const unsigned blocks = static_cast<unsigned>((n + 127) / 128);
     if (ctx->wide)
-        hipLaunchKernelGGL(p1_covariance_kernel<uint64_t>, dim3(blocks), dim3(128), 0, ctx->stream,
+        MXX_LAUNCH(p1_covariance_kernel<uint64_t>, dim3(blocks), dim3(128), 0, ctx->stream,
                            static_cast<const uint64_t *>(a_mat->data), static_cast<const uint64_t *>(b_mat->data),
                            static_cast<const uint64_t *>(d_mat->data), (uint32_t)d, L, (uint32_t)n, ctx->moduli[0],
                            sigma, s, dgg_stddev, static_cast<double *>(cov_ws), cache->sqrt_var, cache->update_coeff);
     else
-        hipLaunchKernelGGL(p1_covariance_kernel<uint32_t>, dim3(blocks), dim3(128), 0, ctx->stream,
+        MXX_LAUNCH(p1_covariance_kernel<uint32_t>, dim3(blocks), dim3(128), 0, ctx->stream,
                            static_cast<const uint32_t *>(a_mat->data), static_cast<const uint32_t *>(b_mat->data),
                            static_cast<const uint32_t *>(d_mat->data), (uint32_t)d, L, (uint32_t)n, ctx->moduli[0],
                            sigma, s, dgg_stddev, static_cast<double *>(cov_ws), cache->sqrt_var, cache->update_coeff);
-    hipLaunchKernelGGL(p1_divisor_kernel, dim3(static_cast<unsigned>((n * m + 255) / 256)), dim3(256), 0, ctx->stream,
+    MXX_LAUNCH(p1_divisor_kernel, dim3(static_cast<unsigned>((n * m + 255) / 256)), dim3(256), 0, ctx->stream,
                        static_cast<KarneyDivisor *>(kd), cache->sqrt_var, n * m);
     hipError_t e = hipGetLastError();
     ctx_free(ctx, cov_ws);
@@ -797,7 +797,7 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
         const uint32_t per_lane =                                                                                 \
             sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM>), ctx->device, ctx->env.sampler_per_lane); \
         const unsigned lblocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));        \
-        hipLaunchKernelGGL((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(256), 0, ctx->stream,          \
+        MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(256), 0, ctx->stream,          \
                            static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,    \
                            cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m, \
                            (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane);          \
@@ -824,7 +824,7 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
     void *mean_ws = nullptr;
     if (m > 8 && ctx_alloc(ctx, total * m * sizeof(double), &mean_ws)) return 1;
 #define LAUNCH_P1(WT, MAXM)                                                                                       \
-    hipLaunchKernelGGL((p1_sample_kernel<WT, MAXM>), dim3(blocks), dim3(128), 0, ctx->stream,                      \
+    MXX_LAUNCH((p1_sample_kernel<WT, MAXM>), dim3(blocks), dim3(128), 0, ctx->stream,                      \
                        static_cast<WT *>(out->data), static_cast<const WT *>(tp2->data), ctx->d_limbs,             \
                        cache->sqrt_var, cache->update_coeff, (uint32_t)m, (uint32_t)cols, L, N, ctx->moduli[0],    \
                        c_scale, seed, static_cast<double *>(mean_ws))

@@ -52,8 +52,9 @@ def _bincode_read_varint(data: bytes, pos: int):
 
 
 class GpuP1CovarianceCache:
-    def __init__(self, raw):
+    def __init__(self, raw, params=None):
         self.raw = raw
+        self.params = params  # the C object frees into its context's allocator: the context must outlive it (the Rust side holds an Arc)
         self._finalizer = weakref.finalize(self, _ffi.lib().gpu_matrix_destroy_p1_covariance_cache, raw)
 
 
@@ -916,7 +917,7 @@ class GpuDCRTPolyMatrix:
         raw = C.c_void_p()
         st = _ffi.lib().gpu_matrix_create_p1_covariance_cache(a_mat.raw, b_mat.raw, d_mat.raw, sigma, s, dgg_stddev, C.byref(raw))
         check_status(st, "gpu_matrix_create_p1_covariance_cache")
-        return GpuP1CovarianceCache(raw)
+        return GpuP1CovarianceCache(raw, a_mat.params)
 
     @staticmethod
     def sample_p1_full_cached(cache: GpuP1CovarianceCache, tp2, seed: GpuRngSeed) -> "GpuDCRTPolyMatrix":
