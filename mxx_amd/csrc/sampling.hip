@@ -193,6 +193,9 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         return set_error("gpu_matrix_sample_distribution: sigma must be positive for Gaussian sampling");
     if (col_offset + out->cols > full_ncol)
         return set_error("gpu_matrix_sample_distribution_columns: column window out of range");
+    // stream ids (global polynomial index + 1) are 48 bits wide in the nonce layout of rng.h: refuse what would wrap
+    if (full_ncol && (out->rows > ((size_t(1) << 48) - 2) / full_ncol))
+        return set_error("gpu_matrix_sample_distribution: matrix too large for the RNG's 48-bit stream ids");
     GpuContext *ctx = out->ctx;
     out->format = keep_coeff ? GPU_POLY_FORMAT_COEFF : GPU_POLY_FORMAT_EVAL;
     const size_t polys = matrix_polys(out);
