@@ -249,17 +249,24 @@ typedef struct {
     uint64_t *fwd, *fwds, *inv, *invs;
     uint64_t n_inv;
 } tab_t;
-static tab_t g_tabs[256];
-static int g_ntabs = 0;
+/* entries are allocated one by one and never move (callers keep the pointer); the index grows by doubling - a fixed
+ * 256-entry array overflowed (NULL table, crash) once the GPU suite visited more than 256 (modulus, ring) pairs */
+static tab_t **g_tabs = NULL;
+static int g_ntabs = 0, g_tabs_cap = 0;
 
 static const tab_t *get_tab(uint64_t q, uint32_t n) {
     const tab_t *found = NULL;
 #pragma omp critical(orc_tab)
     {
         for (int i = 0; i < g_ntabs; ++i)
-            if (g_tabs[i].q == q && g_tabs[i].n == n) { found = &g_tabs[i]; break; }
-        if (!found && g_ntabs < 256) {
-            tab_t *t = &g_tabs[g_ntabs];
+            if (g_tabs[i]->q == q && g_tabs[i]->n == n) { found = g_tabs[i]; break; }
+        if (!found) {
+            if (g_ntabs == g_tabs_cap) {
+                g_tabs_cap = g_tabs_cap ? 2 * g_tabs_cap : 64;
+                g_tabs = realloc(g_tabs, sizeof(tab_t *) * (size_t)g_tabs_cap);
+            }
+            tab_t *t = malloc(sizeof(tab_t));
+            g_tabs[g_ntabs] = t;
             t->q = q; t->n = n;
             t->fwd = malloc(sizeof(uint64_t) * n); t->fwds = malloc(sizeof(uint64_t) * n);
             t->inv = malloc(sizeof(uint64_t) * n); t->invs = malloc(sizeof(uint64_t) * n);

@@ -65,6 +65,32 @@ def test_ntt_intt_vs_oracle(gpu, oracle, n, depth, bits, base):
     assert np.array_equal(mt.to_rns(), oracle.matrix_ntt(top, moduli))
 
 
+@pytest.mark.parametrize("bits", [17, 30, 51, 61])
+@pytest.mark.parametrize("logn", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_ntt_small_rings(gpu, oracle, hip_env, logn, bits):
+    """n = 2..512 (the reference's unit-test rings and BASELINE configs[4]'s n = 256) in both word widths, moduli from 17 to
+    61 bits, 63 vectors per call, extreme residues, both directions - against the CPU restatement, default dispatch and
+    the forced generic kernel.  (A wave-per-vector kernel for these sizes was built in round 3 and measured slower than
+    the 128-thread LDS kernel - profiles/r03_notes.md - so both dispatches currently land on the same kernel.)"""
+    n = 1 << logn
+    depth = 3
+    moduli = oracle.gen_crt_basis(n, depth, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 4)
+    x = rand_matrix(oracle, 40 + logn, 3, 7, moduli, n)     # 63 vectors: never a whole number of waves' worth below 64 points
+    x[0, 0] = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(-1, 1)
+    x[0, 1] = 0
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    ev = oracle.matrix_ntt(x, moduli)
+    assert np.array_equal(m.to_rns(), ev)
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+    hip_env.set("MXX_HIP_NTT_PATH", "generic")
+    g = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    g.ntt_all_in_place()
+    assert np.array_equal(g.to_rns(), ev)
+
+
 @pytest.mark.parametrize("path", ["generic", "global"])
 @pytest.mark.parametrize("n,depth,bits,base", [(128, 2, 17, 1), (1024, 3, 24, 12), (1024, 5, 51, 17)])
 def test_ntt_alternate_kernels(gpu, oracle, hip_env, path, n, depth, bits, base):
