@@ -216,3 +216,29 @@ class GpuDCRTPolyTrapdoorSampler:
             for f in [pool.submit(run, items) for items in groups.values()]:
                 f.result()  # re-raises a worker's exception
         return results
+
+    def preimage_column_sharded(self, comm, shards):
+        """One preimage of a wide target over several device contexts: `shards` = [(params, trapdoor, A, target columns
+        of that context), ...] in communicator order (the trapdoor and A replicated with `to_params`).  Every context
+        samples its column block concurrently - a worker thread per context, as `preimage_batched_sharded` - and ONE
+        all-gather through the C ABI (`gpupoly_matrix_all_gather_columns`: RCCL on the contexts' own streams) leaves the
+        whole preimage on every device.  The reference's fan-out (gpu.rs:371-397) returns the blocks to the host
+        instead; INTEGRATION.md shows the Rust form."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        assert len(shards) == len(comm), "one shard per context of the communicator"
+
+        def run(item):
+            p, td, a, t = item
+            if t.col_size() == 0:
+                k = p.modulus_digits()
+                return GpuDCRTPolyMatrix(p, a.row_size() * (k + 2), 0, p.crt_depth() - 1, True)
+            return self.preimage(p, td, a, t)
+
+        if len(shards) == 1:
+            blocks = [run(shards[0])]
+        else:
+            with ThreadPoolExecutor(max_workers=len(shards)) as pool:
+                blocks = list(pool.map(run, shards))
+        return comm.all_gather_columns(blocks)
+

@@ -146,4 +146,15 @@ def test_sharded_product_and_preimage_gathered_in_process(gpu, oracle):
     fulls = comm.all_gather_columns(xs)
     for pub, f in zip(pubs, fulls):
         assert f.ncol == 5 and pub * f == gpu.GpuDCRTPolyMatrix.from_rns(f.params, t_rns, True)
+    # the same as one call of the host mirror (an empty shard included)
+    comm3 = GpuComm(ps + [gpu.GpuDCRTPolyParams(n, moduli, 12, gpu_ids=ps[0].gpu_ids(), dnum=177)])
+    p2 = comm3.params[2]
+    cuts = [(0, 3), (3, 5), (5, 5)]
+    shards = [(p, td0 if p is ps[0] else td0.to_params(p), a0 if p is ps[0] else a0.to_params(p),
+               gpu.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(t_rns[:, lo:hi]), True)) for p, (lo, hi) in zip(comm3.params, cuts)]
+    fulls = sampler.preimage_column_sharded(comm3, shards)
+    assert len(fulls) == 3 and fulls[2].params is p2
+    for (p, _, a, _), f in zip(shards, fulls):
+        assert f.ncol == 5 and a * f == gpu.GpuDCRTPolyMatrix.from_rns(p, t_rns, True)
+    comm3.close()
     comm.close()
