@@ -68,3 +68,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_ffi.GpuPolyError):
         _ffi.lib()
+
+
+def test_header_compiles_as_c_and_links(tmp_path):
+    """include/gpupoly.h is a plain C header (what a cgo / bindgen / FFI consumer parses): a C translation unit that
+    takes the address of every declared entry point compiles with gcc -std=c99 -pedantic and links against libgpupoly."""
+    import subprocess
+
+    from mxx_amd import _ffi
+
+    syms = header_symbols()
+    src = tmp_path / "link_all.c"
+    body = "\n".join(f"    p[{i}] = (void (*)(void))&{s};" for i, s in enumerate(syms))
+    src.write_text('#include "gpupoly.h"\n#include <stdio.h>\nint main(void) {\n    void (*p[%d])(void);\n%s\n'
+                   '    GpuBatchOp op; GpuRngSeed seed; op.kind = GPUPOLY_OP_ADD; seed.words[0] = 1; (void)op; (void)seed;\n'
+                   '    printf("%%d symbols, version %%s\\n", %d, gpupoly_version());\n    return p[0] == 0;\n}\n' % (len(syms), body, len(syms)))
+    exe = tmp_path / "link_all"
+    libdir = os.path.dirname(_ffi.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-lgpupoly", "-L/opt/rocm/lib", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH=f"{libdir}:/opt/rocm/lib"))
+    assert run.returncode == 0 and f"{len(syms)} symbols" in run.stdout, (run.stdout, run.stderr[-2000:])
