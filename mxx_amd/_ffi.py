@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpupoly.so")
+# MXX_GPUPOLY_LIB: another build of the same library (same-box A/B runs of kernel variants: tools/ab_*.sh)
+LIB_PATH = os.environ.get("MXX_GPUPOLY_LIB") or os.path.join(_HERE, "libgpupoly.so")
 
 GPU_POLY_FORMAT_COEFF = 0
 GPU_POLY_FORMAT_EVAL = 1

@@ -122,13 +122,15 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
     }
 }
 
-template <typename W>
+template <typename W, bool NT = false>
 struct LoadVector {
     const W *g;
-    __device__ __forceinline__ W operator()(uint32_t e) const { return g[e]; }
+    __device__ __forceinline__ W operator()(uint32_t e) const { return nt_load<NT, W>(g + e); }
 };
 
-template <typename W, bool TIGHT = false>
+// NT: non-temporal loads and stores of the data vector - for batches no cache level can hold (the launcher sets it from
+// 1 GiB, as for the whole-vector LDS kernels): the stream then does not displace the twiddle tables
+template <typename W, bool TIGHT = false, bool NT = false>
 __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                uint32_t L) {
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     const size_t vec = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * L + limb;
     const LimbConst lc = limbs[limb];
     W *g = data + vec * N;
-    fwd_body<W, TIGHT, false>(g, LoadVector<W>{g}, tw_all, lc, limb);
+    fwd_body<W, TIGHT, NT>(g, LoadVector<W, NT>{g}, tw_all, lc, limb);
 }
 
 // Gadget decomposition fused into the transform's load (decompose.hip): output vector
@@ -202,7 +204,8 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
 // into the last stage's constants: the MULW launch passes ctx->d_limbs_r, whose n_inv / inv_last_w are multiplied by
 // 2^32 mod q.  PF: the next group's operands are requested before this group's butterflies start.
 // CAP: bound-exponent cap of the unsigned butterflies (kTightCap for 26..28-bit moduli, ntt_lds.h)
-template <typename W, bool SGN, bool MULW = false, int CAP = 31, int WPS = ((SGN && !MULW) ? 8 : 6)>
+// NT: non-temporal loads / stores of the data vector (batches of at least 1 GiB, set by the launcher)
+template <typename W, bool SGN, bool MULW = false, int CAP = 31, int WPS = ((SGN && !MULW) ? 8 : 6), bool NT = false>
 __global__ void __launch_bounds__(512, WPS / (sizeof(W) / 4))
     inv_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
                uint32_t L, const W *in = nullptr, const W *__restrict__ mulw = nullptr) {
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(512, WPS / (sizeof(W) / 4))
             } else {
                 const W *src = g + B * BLK + 8 * lane;
 #pragma unroll
-                for (int m = 0; m < 8; m += VN) *reinterpret_cast<V16 *>(&v[m]) = *reinterpret_cast<const V16 *>(src + m);
+                for (int m = 0; m < 8; m += VN) nt_load16<NT, W>(&v[m], src + m);
             }
             if constexpr (SGN) {  // canonical inputs (exponent 0); keep exponents <= 2
                 gs_network_signed<3, false>(v, tw, B * 64u + lane, 11, q, lc);
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(512, WPS / (sizeof(W) / 4))
     if constexpr (SGN) gs_network_signed<5, true>(h, tw, 0, 0, q, lc);
     else gs_network_lazy<W, 5, true, CAP>(h, tw, 0, 0, q, lc);
 #pragma unroll
-    for (int u = 0; u < R0; ++u) g[tid + T * u] = csub<W>(h[u], q);
+    for (int u = 0; u < R0; ++u) nt_store<NT, W>(csub<W>(h[u], q), g + tid + T * u);
 }
 
 static inline size_t lds_bytes(size_t word) { return 2 * GROUP_WORDS * word; }

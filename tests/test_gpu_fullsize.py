@@ -119,9 +119,10 @@ def test_m3_preimage_relation_and_norm(gpu, oracle, depth):
     assert 0.9 * width < v[2:].std() < 1.1 * width
 
 
-@pytest.mark.parametrize("logn,bits,polys", [(13, 24, 8192), (15, 28, 2048), (12, 51, 8192)])
+@pytest.mark.parametrize("logn,bits,polys", [(13, 24, 8192), (14, 24, 4096), (15, 28, 2048), (12, 51, 8192)])
 def test_ntt_batches_beyond_the_infinity_cache(gpu, oracle, logn, bits, polys):
-    """Batches of at least 1 GiB take the non-temporal forms of the whole-vector LDS kernels (ntt_lds_dispatch.inc):
+    """Batches of at least 1 GiB take the non-temporal forms of the whole-vector LDS kernels and of the grouped 2^14
+    kernels (ntt_lds_dispatch.inc):
     round trip on the device, the first and last polynomials against the CPU restatement, both directions."""
     n = 1 << logn
     moduli = oracle.gen_crt_basis(n, 4, bits)
