@@ -901,16 +901,36 @@ def main():
         res = run_block(wl, d, steps_, warmup_, repeats_)
         return wl, res
 
+    def independent_units(name):
+        """N > 1, strong run: the same workload once more as the reference itself uses several devices - every rank works on
+        its own full-shape units, nothing is exchanged (gate-parallel circuit evaluation, `preimage_batched_sharded`):
+        weak scaling, reported next to the strong figure"""
+        import copy
+
+        wargs = copy.copy(args)
+        wargs.scaling = "weak"
+        w = WORKLOADS[name](mx, d, wargs, device)
+        w.setup()
+        r = run_block(w, d, steps, warmup, 0)
+        return {"scaling": "weak", "value": r["value"], "ms_per_step": r["ms_per_step"], "units_per_step": w.units,
+                "sharding": w.sharding}
+
     if args.workload == "default":
         wl, res = run("m2a", steps, warmup, args.repeats)
         line = block_json(wl, res, d, args, steps, warmup)
         del wl
+        if d.world > 1 and args.scaling == "strong":
+            line["independent_units"] = independent_units("m2a")
         pre_wl, pre_res = run("m3a", steps, warmup, min(args.repeats, 3))
         pre = block_json(pre_wl, pre_res, d, args, steps, warmup)
         for key in ("n_gpus", "higher_is_better", "vs_baseline", "data", "scaling"):
             pre.pop(key, None)
         pre.pop("roofline", None)
         pre["call_ms_hipevents"] = round(pre_res["kernel_ms"][0], 4)
+        if d.world > 1 and args.scaling == "strong":
+            del pre_wl
+            pre["independent_units"] = independent_units("m3a")
+            pre_wl = None
         if d.world == 1:
             # one rank's share at N = 8 (7 of the 50 columns): what column sharding can reach before any exchange - a
             # call of 7 columns is not 7/50 of a call of 50 (fixed costs, partly filled sampler waves)
