@@ -126,6 +126,8 @@ static int copy_rect(GpuComm *comm, size_t dst_rank, size_t src_rank, char *dst,
     return 0;
 }
 
+extern "C" void gpupoly_comm_destroy(GpuComm *comm);
+
 extern "C" int gpupoly_comm_create(GpuContext *const *ctxs, size_t n, GpuComm **out) {
     ABI_GUARD_BEGIN
     if (!out) return set_error("gpupoly_comm_create: null out");
@@ -146,7 +148,19 @@ extern "C" int gpupoly_comm_create(GpuContext *const *ctxs, size_t n, GpuComm **
     const char *want = std::getenv("MXX_HIP_COMM");  // rccl | peer (default: rccl when every context has its own device)
     const bool force_peer = want && want[0] == 'p', force_rccl = want && want[0] == 'r';
     if (force_rccl && !distinct) return set_error("gpupoly_comm_create: MXX_HIP_COMM=rccl needs one device per context");
-    std::unique_ptr<GpuComm> comm(new GpuComm());
+    // every failure below releases what was created so far (events, RCCL communicators) through the destroy entry point
+    struct CommGuard {
+        GpuComm *c;
+        ~CommGuard() {
+            if (c) gpupoly_comm_destroy(c);
+        }
+        GpuComm *operator->() const { return c; }
+        GpuComm *release() {
+            GpuComm *r = c;
+            c = nullptr;
+            return r;
+        }
+    } comm{new GpuComm()};
     comm->ctxs.assign(ctxs, ctxs + n);
     comm->use_rccl = distinct && !force_peer;
     if (const char *e = std::getenv("MXX_HIP_COMM_COPY")) comm->copy_kernel = e[0] == 'k';
