@@ -45,6 +45,7 @@ struct EnvSwitches {
     bool gsamp_simple = false;    // MXX_HIP_GSAMP=simple
     bool p1_simple = false;       // MXX_HIP_P1=simple
     int sampler_per_lane = 0;     // MXX_HIP_SAMPLER_PER_LANE (0 = sized for one resident round)
+    bool ntt64_int = false;       // MXX_HIP_NTT64=int: 64-bit words keep the integer butterflies (A/B, tests)
     void load();
 };
 
@@ -76,6 +77,10 @@ struct GpuContext {
     bool tight_ok = false;         // 32-bit words, moduli of 26..28 bits: the lazy kernels' TIGHT forms (ntt_lds.h)
     void *d_tw2s_inv = nullptr;    // u32 words, moduli < 2^24: inverse pairs {centred w, floor(w 2^32 / q)} as int32 (ntt14.h)
     bool signed_ok = false;
+    // 64-bit words, every modulus below 2^51: the double-precision transforms of ntt_f64.h
+    void *d_twf_fwd = nullptr, *d_twf_inv = nullptr;  // [limb][N] {w, w / q} as doubles
+    void *d_flimbs = nullptr;                         // [limb] F64Limb
+    bool f64_ok = false;
     uint64_t *d_garner = nullptr;  // [limb][limb] : inverse of q_j mod q_i for j<i
     std::vector<uint64_t> garner_inv;  // host copy
     std::vector<LimbConst> limbs;      // host copy

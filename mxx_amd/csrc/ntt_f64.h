@@ -1,0 +1,252 @@
+// ntt_f64.h — whole-vector negacyclic NTT / INTT for 64-bit residue words whose moduli are below 2^51, computed in
+// DOUBLE PRECISION (round 3).
+//
+// Why: with 64-bit words a lazy butterfly costs ~20 integer VALU instructions (a 64 x 64 high product is four 32-bit
+// multiplies plus carries; two low products; the subtraction), against 5 for 32-bit words, and every one of them is
+// priced ~4.5 SIMD cycles on gfx950 - the 51-bit transforms ran at 2.0-3.0 TB/s, VALU-bound.  An FP64 instruction costs
+// the same as ONE 32-bit multiply.  Residues are exact integers in doubles (|x| < 2^53), and for a table constant w
+//     c = rint(V * (w / q));  h = V * w;  l = fma(V, w, -h);  T = fma(-c, q, h) + l
+// is V w - c q exactly: the FMA recovers the rounding error of the product, h - c q is an integer below 2^53, and so is
+// the final sum.  |T| <= (1/2 + e/2) q for |V| <= e q (the quotient estimate errs by at most 1/2 + e/2).  Six
+// instructions per product; the butterfly A = U + T, B = U - T adds two; values are folded (x - q rint(x / q), three
+// instructions) when the next stage could pass 2^53 - every second stage for 51-bit moduli, once per pass below 2^49.
+// tools/bfly_u64_f64.hip: 54 against 105 cycles per wave-butterfly, bit-exact against 128-bit arithmetic.
+//
+// Same transform, tables (psi = minimum primitive root, bit-reversed order) and three-pass LDS structure as the integer
+// kernels of ntt_lds.h; global data stays uint64_t residues; outputs are canonical and bit-identical to the CPU oracle
+// and to the integer kernels (tests/test_gpu_core.py compares all three).
+#pragma once
+
+#include "ntt_lds.h"
+
+struct TwF {        // twiddle and twiddle / q
+    double w, wi;
+};
+struct F64Limb {    // per limb: q, 1 / q, and the two constants of the last inverse stage with N^-1 folded in
+    double q, qinv;
+    TwF n_inv, last_w;
+};
+
+namespace nttf {
+constexpr int kFolded = 2;  // bound after a fold, in units of q / 4 (|x| <= q / 2; rounding slack lives in ELIM)
+
+__device__ __forceinline__ double mulmod(double v, const TwF t, double q) {
+    const double c = rint(v * t.wi);
+    const double h = v * t.w;
+    const double l = fma(v, t.w, -h);
+    return fma(-c, q, h) + l;
+}
+__device__ __forceinline__ double fold(double x, double q, double qinv) { return fma(-rint(x * qinv), q, x); }
+
+// bound (units of q / 4) of both butterfly outputs when both inputs are at E
+__host__ __device__ constexpr int fwd_next(int E) { return E + 2 + (E + 1) / 2; }  // U + T, |T| <= (1/2 + e/2) q
+__host__ __device__ constexpr int inv_next(int E) { return 2 * E; }               // X + Y, X - Y; the product is smaller
+
+// ---- forward: stages [S_P, S_P + C) on 2^C values, bound E on entry; folds inserted at compile time -----------------
+template <int C, int K, int E, int ELIM>
+struct CtStages {
+    static __device__ __forceinline__ void run(double (&v)[1 << C], const TwF *__restrict__ tw, uint32_t bi, int s_p, double q, double qinv) {
+        if constexpr (K < C) {
+            constexpr bool need = fwd_next(E) > ELIM;
+            constexpr int e_in = need ? kFolded : E;
+            static_assert(fwd_next(e_in) <= ELIM, "a folded input must fit");
+            if constexpr (need) {
+#pragma unroll
+                for (int u = 0; u < (1 << C); ++u) v[u] = fold(v[u], q, qinv);
+            }
+            constexpr int half = 1 << (C - K - 1);
+            const uint32_t tb = (1u << (s_p + K)) + (bi << K);
+#pragma unroll
+            for (int u = 0; u < (1 << C); ++u) {
+                if (u & half) continue;
+                const TwF t = tw[tb + (static_cast<uint32_t>(u) >> (C - K))];
+                const double T = mulmod(v[u + half], t, q);
+                const double U = v[u];
+                v[u] = U + T;
+                v[u + half] = U - T;
+            }
+            CtStages<C, K + 1, fwd_next(e_in), ELIM>::run(v, tw, bi, s_p, q, qinv);
+        }
+    }
+};
+
+// ---- inverse: Gentleman-Sande stages K = C-1 .. 0; LAST: the final stage multiplies both outputs (N^-1 folded in) ---
+template <int C, int K, int E, int ELIM, bool LAST>
+struct GsStages {
+    static __device__ __forceinline__ void run(double (&v)[1 << C], const TwF *__restrict__ tw, uint32_t bi, int s_p, const F64Limb &lc) {
+        if constexpr (K >= 0) {
+            constexpr bool need = inv_next(E) > ELIM;
+            constexpr int e_in = need ? kFolded : E;
+            if constexpr (need) {
+#pragma unroll
+                for (int u = 0; u < (1 << C); ++u) v[u] = fold(v[u], lc.q, lc.qinv);
+            }
+            constexpr int half = 1 << (C - K - 1);
+            const uint32_t tb = (1u << (s_p + K)) + (bi << K);
+#pragma unroll
+            for (int u = 0; u < (1 << C); ++u) {
+                if (u & half) continue;
+                const double X = v[u], Y = v[u + half];
+                const double A = X + Y, D = X - Y;
+                if constexpr (LAST && K == 0) {
+                    v[u] = mulmod(A, lc.n_inv, lc.q);
+                    v[u + half] = mulmod(D, lc.last_w, lc.q);
+                } else {
+                    v[u] = A;
+                    v[u + half] = mulmod(D, tw[tb + (static_cast<uint32_t>(u) >> (C - K))], lc.q);
+                }
+            }
+            GsStages<C, K - 1, inv_next(e_in), ELIM, LAST>::run(v, tw, bi, s_p, lc);
+        }
+    }
+};
+
+__device__ __forceinline__ uint64_t to_residue(double x, double q, double qinv) {  // any bound the folds allow -> [0, q)
+    double r = fold(x, q, qinv);  // [-q/2, q/2] up to the quotient's rounding
+    r = r < 0.0 ? r + q : r;
+    r = r >= q ? r - q : r;
+    return static_cast<uint64_t>(r);
+}
+
+// the transform of one vector: `load(e)` supplies residue e (natural order); canonical residues, bit-reversed, to g
+template <int LOGN, int LOGR, int ELIM, bool NT, typename Load>
+__device__ __forceinline__ void fwd_body(uint64_t *__restrict__ g, const Load load, const TwF *__restrict__ tw, const F64Limb &lc) {
+    typedef NttLdsCfg<uint64_t, LOGN, LOGR, false> Cfg;
+    constexpr uint32_t N = Cfg::N, T = Cfg::T;
+    constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
+    static_assert(P == 3, "three passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *x = reinterpret_cast<double *>(smem);
+    const uint32_t tid = threadIdx.x;
+    const double q = lc.q, qinv = lc.qinv;
+    {   // pass 0: stages [0, LOGR) on elements tid + T u straight from HBM; inputs are residues (bound q: 4 units)
+        double v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = static_cast<double>(load(tid + T * u));
+        CtStages<LOGR, 0, 4, ELIM>::run(v, tw, 0, 0, q, qinv);
+        const uint32_t pb = lds_pad_c(tid);
+#pragma unroll
+        for (int u = 0; u < R; ++u) x[pb + lds_pad_c(T * u)] = fold(v[u], q, qinv);  // every pass hands over folded values
+    }
+    __syncthreads();
+    {   // pass 1: stages [LOGR, 2 LOGR)
+        constexpr uint32_t B = 1u << (LOGN - LOGR), S = B >> LOGR;
+        uint32_t bi, pb;
+        lds_set_addr<uint64_t, LOGN, LOGR, LOGR, LOGR>(tid, 0, bi, pb);
+        double v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
+        CtStages<LOGR, 0, kFolded, ELIM>::run(v, tw, bi, LOGR, q, qinv);
+#pragma unroll
+        for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = fold(v[u], q, qinv);
+    }
+    __syncthreads();
+    uint64_t *xr = reinterpret_cast<uint64_t *>(smem);  // the last pass leaves canonical residues in place
+    {   // pass 2: stages [2 LOGR, LOGN): R contiguous values per thread
+        constexpr int G = 1 << (LOGR - CLAST), E = 1 << CLAST;
+        const uint32_t pb0 = lds_pad_c(tid * R);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            double v[E];
+#pragma unroll
+            for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
+            CtStages<CLAST, 0, kFolded, ELIM>::run(v, tw, tid * G + gi, 2 * LOGR, q, qinv);
+#pragma unroll
+            for (int u = 0; u < E; ++u) xr[pb0 + gi * E + u] = to_residue(v[u], q, qinv);
+        }
+    }
+    __syncthreads();
+    // LDS -> HBM, 16 bytes per lane
+#pragma unroll
+    for (uint32_t jj = 0; jj < N / 2 / T; ++jj) {
+        const uint32_t i = tid + jj * T;
+        nt_store16<NT, uint64_t>(g + static_cast<size_t>(i) * 2, &xr[lds_pad_c(i * 2)]);
+    }
+}
+
+template <int LOGN, int LOGR, int WAVES_PER_EU, int ELIM, bool NT>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
+    fwd_kernel(uint64_t *__restrict__ data, const TwF *__restrict__ tw_all, const F64Limb *__restrict__ limbs, uint32_t L) {
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const F64Limb lc = limbs[limb];
+    uint64_t *g = data + (vec << LOGN);
+    fwd_body<LOGN, LOGR, ELIM, NT>(g, LoadData<uint64_t, NT>{g}, tw_all + (static_cast<size_t>(limb) << LOGN), lc);
+}
+
+// decompose + forward transform (decompose.hip): grid = (L * src_cols, k, source rows), as ntt_fwd_lazy_digits_kernel
+template <int LOGN, int LOGR, int WAVES_PER_EU, int ELIM, bool REDUCE, bool NTS>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
+    fwd_digits_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ coeff, const TwF *__restrict__ tw_all,
+                      const F64Limb *__restrict__ flimbs, const LimbConst *__restrict__ limbs, uint32_t L, uint32_t src_cols,
+                      uint32_t dpt, uint32_t base_bits, uint32_t k) {
+    const uint32_t limb = blockIdx.x % L, col = blockIdx.x / L;
+    const uint32_t td = blockIdx.y, t = td / dpt, d = td - t * dpt;
+    const size_t r = blockIdx.z;
+    const F64Limb lc = flimbs[limb];
+    const uint64_t *src = coeff + (((r * src_cols + col) * L + t) << LOGN);
+    uint64_t *g = out + (((((r * k + td) * src_cols + col) * L) + limb) << LOGN);
+    fwd_body<LOGN, LOGR, ELIM, NTS>(g, load_digit_of<uint64_t, REDUCE>(src, limbs, t, d, base_bits, limbs[limb].q),
+                                    tw_all + (static_cast<size_t>(limb) << LOGN), lc);
+}
+
+template <int LOGN, int LOGR, int WAVES_PER_EU, int ELIM, bool NT>
+__global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
+    inv_kernel(uint64_t *__restrict__ data, const TwF *__restrict__ tw_all, const F64Limb *__restrict__ limbs, uint32_t L) {
+    typedef NttLdsCfg<uint64_t, LOGN, LOGR, true> Cfg;
+    constexpr uint32_t N = Cfg::N, T = Cfg::T;
+    constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
+    static_assert(P == 3, "three passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *xr = reinterpret_cast<uint64_t *>(smem);
+    double *x = reinterpret_cast<double *>(smem);
+    const uint32_t tid = threadIdx.x;
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const F64Limb lc = limbs[limb];
+    const TwF *tw = tw_all + (static_cast<size_t>(limb) << LOGN);
+    uint64_t *g = data + (vec << LOGN);
+    // HBM -> LDS, 16 bytes per lane (residues as they are; converted by the first pass)
+#pragma unroll
+    for (uint32_t jj = 0; jj < N / 2 / T; ++jj) {
+        const uint32_t i = tid + jj * T;
+        nt_load16<NT, uint64_t>(&xr[lds_pad_c(i * 2)], g + static_cast<size_t>(i) * 2);
+    }
+    __syncthreads();
+    {   // contiguous pass: stages [2 LOGR, LOGN) in GS order
+        constexpr int G = 1 << (LOGR - CLAST), E = 1 << CLAST;
+        const uint32_t pb0 = lds_pad_c(tid * R);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            double v[E];
+#pragma unroll
+            for (int u = 0; u < E; ++u) v[u] = static_cast<double>(xr[pb0 + gi * E + u]);
+            GsStages<CLAST, CLAST - 1, 4, ELIM, false>::run(v, tw, tid * G + gi, 2 * LOGR, lc);
+#pragma unroll
+            for (int u = 0; u < E; ++u) x[pb0 + gi * E + u] = fold(v[u], lc.q, lc.qinv);
+        }
+    }
+    __syncthreads();
+    {   // middle pass: stages [LOGR, 2 LOGR)
+        constexpr uint32_t B = 1u << (LOGN - LOGR), S = B >> LOGR;
+        uint32_t bi, pb;
+        lds_set_addr<uint64_t, LOGN, LOGR, LOGR, LOGR>(tid, 0, bi, pb);
+        double v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
+        GsStages<LOGR, LOGR - 1, kFolded, ELIM, false>::run(v, tw, bi, LOGR, lc);
+#pragma unroll
+        for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = fold(v[u], lc.q, lc.qinv);
+    }
+    __syncthreads();
+    {   // strided pass: stages [0, LOGR), N^-1 in the last one, results straight to HBM (coalesced per u)
+        const uint32_t pb = lds_pad_c(tid);
+        double v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(T * u)];
+        GsStages<LOGR, LOGR - 1, kFolded, ELIM, true>::run(v, tw, 0, 0, lc);
+#pragma unroll
+        for (int u = 0; u < R; ++u) nt_store<NT, uint64_t>(to_residue(v[u], lc.q, lc.qinv), g + tid + T * u);
+    }
+}
+}  // namespace nttf

@@ -139,6 +139,7 @@ void EnvSwitches::load() {
     }
     if (const char *e = std::getenv("MXX_HIP_GSAMP")) gsamp_simple = e[0] == 's';
     if (const char *e = std::getenv("MXX_HIP_P1")) p1_simple = e[0] == 's';
+    if (const char *e = std::getenv("MXX_HIP_NTT64")) ntt64_int = e[0] == 'i';
     if (const char *e = std::getenv("MXX_HIP_SAMPLER_PER_LANE")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 4096) sampler_per_lane = v;
@@ -280,6 +281,31 @@ static int upload_tables(GpuContext *ctx, const std::vector<std::vector<uint64_t
     HIP_TRY(hipMalloc(&ctx->d_tw2_inv, 2 * bytes));
     HIP_TRY(hipMemcpy(ctx->d_tw2_fwd, h_pf.data(), 2 * bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tw2_inv, h_pi.data(), 2 * bytes, hipMemcpyHostToDevice));
+    if (sizeof(W) == 8 && ctx->crt_bits <= 51 && N >= 1024 && N <= 16384) {
+        // double-precision tables for ntt_f64.h: {w, w / q} (the quotient of two exactly representable integers is
+        // correctly rounded, so the device sees the same bits on every host)
+        struct HostTwF { double w, wi; };
+        struct HostF64Limb { double q, qinv; HostTwF n_inv, last_w; };
+        std::vector<HostTwF> tf(L * N), ti(L * N);
+        std::vector<HostF64Limb> fl(L);
+        for (size_t l = 0; l < L; ++l) {
+            const double qd = static_cast<double>(ctx->moduli[l]);
+            for (size_t j = 0; j < N; ++j) {
+                tf[l * N + j] = {static_cast<double>(fwd[l][j]), static_cast<double>(fwd[l][j]) / qd};
+                ti[l * N + j] = {static_cast<double>(inv[l][j]), static_cast<double>(inv[l][j]) / qd};
+            }
+            const LimbConst &lc = ctx->limbs[l];
+            fl[l] = {qd, 1.0 / qd, {static_cast<double>(lc.n_inv), static_cast<double>(lc.n_inv) / qd},
+                     {static_cast<double>(lc.inv_last_w), static_cast<double>(lc.inv_last_w) / qd}};
+        }
+        HIP_TRY(hipMalloc(&ctx->d_twf_fwd, sizeof(HostTwF) * L * N));
+        HIP_TRY(hipMalloc(&ctx->d_twf_inv, sizeof(HostTwF) * L * N));
+        HIP_TRY(hipMalloc(&ctx->d_flimbs, sizeof(HostF64Limb) * L));
+        HIP_TRY(hipMemcpy(ctx->d_twf_fwd, tf.data(), sizeof(HostTwF) * L * N, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_twf_inv, ti.data(), sizeof(HostTwF) * L * N, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_flimbs, fl.data(), sizeof(HostF64Limb) * L, hipMemcpyHostToDevice));
+        ctx->f64_ok = true;
+    }
     if (ctx->signed_ok && sizeof(W) == 4) {
         // centred twiddle w^ in (-q/2, q/2] and w^' = floor(w^ * 2^32 / q), both as int32 bit patterns
         auto signed_pair = [](uint64_t w, uint64_t q, W *dst) {
@@ -310,6 +336,9 @@ static void context_release(GpuContext *ctx) {
     for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->d_limbs) (void)hipFree(ctx->d_limbs);
     if (ctx->d_limbs_r) (void)hipFree(ctx->d_limbs_r);
+    if (ctx->d_twf_fwd) (void)hipFree(ctx->d_twf_fwd);
+    if (ctx->d_twf_inv) (void)hipFree(ctx->d_twf_inv);
+    if (ctx->d_flimbs) (void)hipFree(ctx->d_flimbs);
     if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
     if (ctx->d_tw_fwd_sh) (void)hipFree(ctx->d_tw_fwd_sh);
     if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);

@@ -91,6 +91,46 @@ def test_ntt_small_rings(gpu, oracle, hip_env, logn, bits):
     assert np.array_equal(g.to_rns(), ev)
 
 
+@pytest.mark.parametrize("bits", [51, 50, 49, 45, 33])
+@pytest.mark.parametrize("logn", [10, 11, 12, 13, 14])
+def test_ntt_u64_double_precision_kernels(gpu, oracle, hip_env, logn, bits):
+    """64-bit words with moduli below 2^51 take the double-precision transforms (ntt_f64.h: residues as exact integers in
+    doubles, products through FMA, folds inserted at compile time so that nothing reaches 2^53 - every second stage at 51
+    bits, once per pass below 2^49): bit-exact against the CPU restatement and against the integer kernels
+    (MXX_HIP_NTT64=int) on random vectors and on the inputs that maximise every intermediate (all q - 1, alternating
+    0 / q - 1 at several periods, a spike), both directions, and the decomposition fused into the forward transform."""
+    n = 1 << logn
+    moduli = oracle.gen_crt_basis(n, 3, bits)
+    p = gpu.GpuDCRTPolyParams(n, moduli, 17)
+    top = (np.asarray(moduli, dtype=np.uint64) - np.uint64(1)).reshape(1, 1, -1, 1)
+    pats = [rand_matrix(oracle, 170 + logn, 1, 2, moduli, n), np.broadcast_to(top, (1, 1, len(moduli), n)).copy()]
+    for period in (2, 64, n):
+        m = np.broadcast_to(top, (1, 1, len(moduli), n)).copy()
+        m[..., (np.arange(n) // (period // 2)) % 2 == 1] = 0
+        pats.append(m)
+    spike = np.zeros((1, 1, len(moduli), n), dtype=np.uint64)
+    spike[..., n - 1] = top[..., 0]
+    pats.append(spike)
+    x = np.concatenate(pats, axis=1)
+    want = oracle.matrix_ntt(x, moduli)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    m.ntt_all_in_place()
+    assert np.array_equal(m.to_rns(), want)
+    m.intt_all_in_place()
+    assert np.array_equal(m.to_rns(), x)
+    e = gpu.GpuDCRTPolyMatrix.from_rns(p, x, True)  # the same patterns as evaluation-domain inputs of the inverse
+    e.intt_all_in_place()
+    assert np.array_equal(e.to_rns(), oracle.matrix_ntt(x, moduli, inverse=True))
+    dec = gpu.GpuDCRTPolyMatrix.from_rns(p, x[:, :2], False).decompose()
+    want_dec = oracle.matrix_ntt(oracle.decompose(x[:, :2], moduli, 17), moduli)
+    assert np.array_equal(dec.to_rns(), want_dec)
+    hip_env.set("MXX_HIP_NTT64", "int")
+    mi = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    mi.ntt_all_in_place()
+    assert np.array_equal(mi.to_rns(), want)
+    assert np.array_equal(gpu.GpuDCRTPolyMatrix.from_rns(p, x[:, :2], False).decompose().to_rns(), want_dec)
+
+
 @pytest.mark.parametrize("path", ["generic", "global"])
 @pytest.mark.parametrize("n,depth,bits,base", [(128, 2, 17, 1), (1024, 3, 24, 12), (1024, 5, 51, 17)])
 def test_ntt_alternate_kernels(gpu, oracle, hip_env, path, n, depth, bits, base):
