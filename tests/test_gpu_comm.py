@@ -80,6 +80,25 @@ def test_all_gather_columns_contexts_sharing_a_device(gpu, oracle, monkeypatch, 
     comm.close()
 
 
+def test_all_gather_columns_eight_contexts_bench_partitions(gpu, oracle):
+    """The partitions an 8-GPU node sees, with eight contexts on the one device: the preimage's 22 x 50 matrix split
+    7,7,6,6,6,6,6,6 (uneven, staged / 2-D copies) and the product's 1 x 120 split 15 x 8 (equal, straight into place)."""
+    from mxx_amd.parallel import GpuComm, all_shard_ranges
+
+    ps = contexts_on_one_device(gpu, oracle, 8, n=256, depth=2)
+    comm = GpuComm(ps)
+    moduli, n = ps[0].moduli(), 256
+    for rows, cols in ((22, 50), (1, 120)):
+        x = rand_matrix(oracle, 990 + rows, rows, cols, moduli, n)
+        ranges = all_shard_ranges(cols, 8)
+        assert [len(r) for r in ranges] == ([7, 7, 6, 6, 6, 6, 6, 6] if cols == 50 else [15] * 8)
+        blocks = [gpu.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(x[:, r.start:r.stop]), True) for p, r in zip(ps, ranges)]
+        fulls = comm.all_gather_columns(blocks)
+        for f in fulls:
+            assert np.array_equal(f.to_rns(), x)
+    comm.close()
+
+
 def test_all_gather_columns_rejects_bad_arguments(gpu, oracle):
     from mxx_amd import _ffi
     from mxx_amd.parallel import GpuComm
