@@ -47,3 +47,15 @@ for name, n, depth, bits, base in CASES:
         gadget_eval=O.gadget_matrix(2, moduli, n, base),
     )
     print("wrote", name)
+
+# seeded samplers (round 3 keying: eight draws per ChaCha20 block for uniform / bit / ternary, a stream per coefficient
+# for the Gaussian): a 2 x 3 matrix and a column window of it, n = 16, three 18-bit limbs, plus a 51-bit pair
+SEED = bytes((7 * i + 3) & 0xFF for i in range(32))
+for name, n, depth, bits in (("samplers_n16_d3_b18", 16, 3, 18), ("samplers_n8_d2_b51", 8, 2, 51)):
+    moduli = O.gen_crt_basis(n, depth, bits)
+    out = {"moduli": np.asarray(moduli, dtype=np.uint64), "n": n, "seed": np.frombuffer(SEED, dtype=np.uint8)}
+    for dist, sigma in (("uniform", 0.0), ("bit", 0.0), ("ternary", 0.0), ("gauss", 4.578)):
+        out[dist] = O.sample_distribution(2, 3, moduli, n, dist, sigma, SEED)
+        out[dist + "_window"] = O.sample_distribution(2, 2, moduli, n, dist, sigma, SEED, full_ncol=3, col_offset=1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)

@@ -369,7 +369,7 @@ def test_matmul_is_ring_product(gpu, oracle):
 def test_golden_fixtures_on_gpu(gpu, oracle):
     gdir = os.path.join(os.path.dirname(__file__), "golden")
     for f in sorted(os.listdir(gdir)):
-        if not f.endswith(".npz"):
+        if not f.endswith(".npz") or f.startswith("samplers_"):  # the sampler fixtures: tests/test_gpu_sampling.py
             continue
         z = np.load(os.path.join(gdir, f))
         moduli = [int(q) for q in z["moduli"]]

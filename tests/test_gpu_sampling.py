@@ -25,6 +25,25 @@ def seed(gpu, salt=0):
     return gpu.GpuRngSeed.from_bytes(bytes(b))
 
 
+def test_sampler_golden_fixtures_on_gpu(gpu, oracle):
+    """The committed sampler fixtures (tests/golden/samplers_*.npz) against the device: every distribution, the full
+    matrix and its column window."""
+    import os
+
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    for f in sorted(x for x in os.listdir(gdir) if x.startswith("samplers_")):
+        z = np.load(os.path.join(gdir, f))
+        moduli, n = [int(q) for q in z["moduli"]], int(z["n"])
+        p = gpu.GpuDCRTPolyParams(n, moduli, 6)
+        s = gpu.GpuRngSeed.from_bytes(bytes(z["seed"]))
+        for dist, sigma in (("uniform", 0.0), ("bit", 0.0), ("ternary", 0.0), ("gauss", 4.578)):
+            code = oracle.DIST[dist]
+            m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, code, sigma, s)
+            assert np.array_equal(m.to_coeff_rns(), z[dist]), (f, dist)
+            w = gpu.GpuDCRTPolyMatrix.sample_distribution_columns(p, 2, 3, 1, 2, code, sigma, s)
+            assert np.array_equal(w.to_coeff_rns(), z[dist + "_window"]), (f, dist)
+
+
 def test_uniform_sampler_overflow_streams_bit_exact(gpu, oracle):
     """Moduli that reject one 64-bit draw in nine: the rare path of the block-per-eight-draws uniform sampler (the
     coefficient's overflow stream) runs hundreds of times and must agree with the CPU restatement; windows commute."""

@@ -147,7 +147,7 @@ def test_crt_reconstruct():
 def test_golden_fixtures_match_oracle():
     """Committed fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py)."""
     gdir = os.path.join(os.path.dirname(__file__), "golden")
-    files = sorted(f for f in os.listdir(gdir) if f.endswith(".npz"))
+    files = sorted(f for f in os.listdir(gdir) if f.endswith(".npz") and not f.startswith("samplers_"))
     assert files, "no golden fixtures committed"
     for f in files:
         z = np.load(os.path.join(gdir, f))
@@ -162,3 +162,17 @@ def test_golden_fixtures_match_oracle():
         c0 = O.negacyclic_schoolbook(a0, b0, q0)
         prod = O.pointwise("mul", z["a_eval"][:1, :1], z["b_eval"][:1, :1], moduli)
         assert np.array_equal(O.matrix_ntt(prod, moduli, inverse=True)[0, 0, 0], c0)
+
+
+def test_golden_sampler_fixtures_match_oracle():
+    """tests/golden/samplers_*.npz pin the seeded samplers' keying (round 3) as data: every distribution and its column
+    window, 18-bit and 51-bit limbs."""
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    files = sorted(f for f in os.listdir(gdir) if f.startswith("samplers_"))
+    assert len(files) >= 2
+    for f in files:
+        z = np.load(os.path.join(gdir, f))
+        moduli, n, seed = [int(q) for q in z["moduli"]], int(z["n"]), bytes(z["seed"])
+        for dist, sigma in (("uniform", 0.0), ("bit", 0.0), ("ternary", 0.0), ("gauss", 4.578)):
+            assert np.array_equal(O.sample_distribution(2, 3, moduli, n, dist, sigma, seed), z[dist]), (f, dist)
+            assert np.array_equal(z[dist + "_window"], z[dist][:, 1:3]), (f, dist)
