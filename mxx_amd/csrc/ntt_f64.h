@@ -108,9 +108,15 @@ __device__ __forceinline__ uint64_t to_residue(double x, double q, double qinv) 
     return static_cast<uint64_t>(r);
 }
 
-// the transform of one vector: `load(e)` supplies residue e (natural order); canonical residues, bit-reversed, to g
-template <int LOGN, int LOGR, int ELIM, bool NT, typename Load>
-__device__ __forceinline__ void fwd_body(uint64_t *__restrict__ g, const Load load, const TwF *__restrict__ tw, const F64Limb &lc) {
+// what the split kernels hand over in the matrix's own 8-byte slots between their two launches: folded doubles
+__device__ __forceinline__ double raw_f64(uint64_t bits) { return __longlong_as_double(static_cast<long long>(bits)); }
+__device__ __forceinline__ uint64_t f64_raw(double x) { return static_cast<uint64_t>(__double_as_longlong(x)); }
+
+// the transform of one (sub-)vector: `load(e)` supplies residue e (natural order); canonical residues, bit-reversed, to g.
+// PRE > 0 (rings beyond LDS, as ntt_lds.h): the vector has 2^(LOGN + PRE) points, head_kernel did its first PRE stages and
+// left folded doubles; this workgroup transforms sub-vector `sub`, twiddles at stage PRE + s, block (sub << s) + b.
+template <int LOGN, int LOGR, int PRE, int ELIM, bool NT, typename Load>
+__device__ __forceinline__ void fwd_body(uint64_t *__restrict__ g, const Load load, const TwF *__restrict__ tw, const F64Limb &lc, uint32_t sub) {
     typedef NttLdsCfg<uint64_t, LOGN, LOGR, false> Cfg;
     constexpr uint32_t N = Cfg::N, T = Cfg::T;
     constexpr int P = Cfg::P, CLAST = Cfg::CLAST, R = 1 << LOGR;
@@ -122,8 +128,8 @@ __device__ __forceinline__ void fwd_body(uint64_t *__restrict__ g, const Load lo
     {   // pass 0: stages [0, LOGR) on elements tid + T u straight from HBM; inputs are residues (bound q: 4 units)
         double v[R];
 #pragma unroll
-        for (int u = 0; u < R; ++u) v[u] = static_cast<double>(load(tid + T * u));
-        CtStages<LOGR, 0, 4, ELIM>::run(v, tw, 0, 0, q, qinv);
+        for (int u = 0; u < R; ++u) v[u] = PRE > 0 ? raw_f64(load(tid + T * u)) : static_cast<double>(load(tid + T * u));
+        CtStages<LOGR, 0, (PRE > 0 ? kFolded : 4), ELIM>::run(v, tw, sub, PRE, q, qinv);
         const uint32_t pb = lds_pad_c(tid);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(T * u)] = fold(v[u], q, qinv);  // every pass hands over folded values
@@ -136,7 +142,7 @@ __device__ __forceinline__ void fwd_body(uint64_t *__restrict__ g, const Load lo
         double v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
-        CtStages<LOGR, 0, kFolded, ELIM>::run(v, tw, bi, LOGR, q, qinv);
+        CtStages<LOGR, 0, kFolded, ELIM>::run(v, tw, (sub << LOGR) + bi, PRE + LOGR, q, qinv);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = fold(v[u], q, qinv);
     }
@@ -150,7 +156,7 @@ __device__ __forceinline__ void fwd_body(uint64_t *__restrict__ g, const Load lo
             double v[E];
 #pragma unroll
             for (int u = 0; u < E; ++u) v[u] = x[pb0 + gi * E + u];
-            CtStages<CLAST, 0, kFolded, ELIM>::run(v, tw, tid * G + gi, 2 * LOGR, q, qinv);
+            CtStages<CLAST, 0, kFolded, ELIM>::run(v, tw, (sub << (2 * LOGR)) + tid * G + gi, PRE + 2 * LOGR, q, qinv);
 #pragma unroll
             for (int u = 0; u < E; ++u) xr[pb0 + gi * E + u] = to_residue(v[u], q, qinv);
         }
@@ -164,14 +170,73 @@ __device__ __forceinline__ void fwd_body(uint64_t *__restrict__ g, const Load lo
     }
 }
 
-template <int LOGN, int LOGR, int WAVES_PER_EU, int ELIM, bool NT>
+template <int LOGN, int LOGR, int WAVES_PER_EU, int ELIM, bool NT, int PRE = 0>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     fwd_kernel(uint64_t *__restrict__ data, const TwF *__restrict__ tw_all, const F64Limb *__restrict__ limbs, uint32_t L) {
-    const size_t vec = blockIdx.x;
+    const size_t vec = blockIdx.x >> PRE;
+    const uint32_t sub = blockIdx.x & ((1u << PRE) - 1u);
     const uint32_t limb = static_cast<uint32_t>(vec % L);
     const F64Limb lc = limbs[limb];
-    uint64_t *g = data + (vec << LOGN);
-    fwd_body<LOGN, LOGR, ELIM, NT>(g, LoadData<uint64_t, NT>{g}, tw_all + (static_cast<size_t>(limb) << LOGN), lc);
+    uint64_t *g = data + (vec << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
+    fwd_body<LOGN, LOGR, PRE, ELIM, NT>(g, LoadData<uint64_t, NT>{g}, tw_all + (static_cast<size_t>(limb) << (LOGN + PRE)), lc, sub);
+}
+
+// rings beyond LDS, forward: stages [0, PRE) on the strided sets {j + (N >> PRE) u}; folded doubles go back into the
+// vector's own slots for the sub-vector kernels.  DIGITS: the gadget decomposition in the load (grid and indexing of
+// ntt_fwd_head_digits_kernel)
+template <int PRE, int ELIM, bool DIGITS, bool REDUCE, bool NTS>
+__global__ void __launch_bounds__(256)
+    head_kernel(uint64_t *__restrict__ out, const uint64_t *__restrict__ coeff, const TwF *__restrict__ tw_all,
+                const F64Limb *__restrict__ flimbs, const LimbConst *__restrict__ limbs, uint32_t L, uint32_t logN, uint32_t src_cols,
+                uint32_t dpt, uint32_t base_bits, uint32_t k) {
+    constexpr int R = 1 << PRE;
+    const uint32_t S = (1u << logN) >> PRE;
+    const uint32_t sets_blocks = S / blockDim.x;
+    uint32_t limb, j;
+    uint64_t *g;
+    const uint64_t *src;
+    uint32_t sh = 0;
+    uint64_t mask = ~0ull, qred = 0;
+    if constexpr (DIGITS) {
+        const uint32_t sb = blockIdx.x % sets_blocks, rest = blockIdx.x / sets_blocks;
+        limb = rest % L;
+        const uint32_t col = rest / L;
+        const uint32_t td = blockIdx.y, t = td / dpt, d = td - t * dpt;
+        const size_t r = blockIdx.z;
+        j = sb * blockDim.x + threadIdx.x;
+        const uint32_t src_bits = limbs[t].kbits, shift = d * base_bits;
+        mask = 0;
+        if (shift < src_bits && shift < 64) {
+            const uint32_t rem = src_bits - shift;
+            const uint32_t db = base_bits < rem ? base_bits : rem;
+            mask = db >= 64 ? ~0ull : ((1ull << db) - 1);
+        }
+        sh = shift < 64 ? shift : 0;
+        qred = limbs[limb].q;
+        src = coeff + (((r * src_cols + col) * L + t) << logN) + j;
+        g = out + (((((r * k + td) * src_cols + col) * L) + limb) << logN) + j;
+    } else {
+        const size_t vec = blockIdx.x / sets_blocks;
+        j = (blockIdx.x - static_cast<uint32_t>(vec) * sets_blocks) * blockDim.x + threadIdx.x;
+        limb = static_cast<uint32_t>(vec % L);
+        g = out + (vec << logN) + j;
+        src = g;
+    }
+    const F64Limb lc = flimbs[limb];
+    const TwF *tw = tw_all + (static_cast<size_t>(limb) << logN);
+    double v[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        uint64_t x = src[static_cast<size_t>(S) * u];
+        if constexpr (DIGITS) {
+            x = (x >> sh) & mask;
+            if constexpr (REDUCE) x = x >= qred ? x % qred : x;
+        }
+        v[u] = static_cast<double>(x);
+    }
+    CtStages<PRE, 0, 4, ELIM>::run(v, tw, 0, 0, lc.q, lc.qinv);
+#pragma unroll
+    for (int u = 0; u < R; ++u) nt_store<NTS, uint64_t>(f64_raw(fold(v[u], lc.q, lc.qinv)), g + static_cast<size_t>(S) * u);
 }
 
 // decompose + forward transform (decompose.hip): grid = (L * src_cols, k, source rows), as ntt_fwd_lazy_digits_kernel
@@ -186,11 +251,12 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     const F64Limb lc = flimbs[limb];
     const uint64_t *src = coeff + (((r * src_cols + col) * L + t) << LOGN);
     uint64_t *g = out + (((((r * k + td) * src_cols + col) * L) + limb) << LOGN);
-    fwd_body<LOGN, LOGR, ELIM, NTS>(g, load_digit_of<uint64_t, REDUCE>(src, limbs, t, d, base_bits, limbs[limb].q),
-                                    tw_all + (static_cast<size_t>(limb) << LOGN), lc);
+    fwd_body<LOGN, LOGR, 0, ELIM, NTS>(g, load_digit_of<uint64_t, REDUCE>(src, limbs, t, d, base_bits, limbs[limb].q),
+                                       tw_all + (static_cast<size_t>(limb) << LOGN), lc, 0u);
 }
 
-template <int LOGN, int LOGR, int WAVES_PER_EU, int ELIM, bool NT>
+// PRE > 0: the last PRE stages and the N^-1 scaling are tail_kernel's; this kernel then leaves folded doubles
+template <int LOGN, int LOGR, int WAVES_PER_EU, int ELIM, bool NT, int PRE = 0>
 __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     inv_kernel(uint64_t *__restrict__ data, const TwF *__restrict__ tw_all, const F64Limb *__restrict__ limbs, uint32_t L) {
     typedef NttLdsCfg<uint64_t, LOGN, LOGR, true> Cfg;
@@ -201,11 +267,12 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
     uint64_t *xr = reinterpret_cast<uint64_t *>(smem);
     double *x = reinterpret_cast<double *>(smem);
     const uint32_t tid = threadIdx.x;
-    const size_t vec = blockIdx.x;
+    const size_t vec = blockIdx.x >> PRE;
+    const uint32_t sub = blockIdx.x & ((1u << PRE) - 1u);
     const uint32_t limb = static_cast<uint32_t>(vec % L);
     const F64Limb lc = limbs[limb];
-    const TwF *tw = tw_all + (static_cast<size_t>(limb) << LOGN);
-    uint64_t *g = data + (vec << LOGN);
+    const TwF *tw = tw_all + (static_cast<size_t>(limb) << (LOGN + PRE));
+    uint64_t *g = data + (vec << (LOGN + PRE)) + (static_cast<size_t>(sub) << LOGN);
     // HBM -> LDS, 16 bytes per lane (residues as they are; converted by the first pass)
 #pragma unroll
     for (uint32_t jj = 0; jj < N / 2 / T; ++jj) {
@@ -221,7 +288,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
             double v[E];
 #pragma unroll
             for (int u = 0; u < E; ++u) v[u] = static_cast<double>(xr[pb0 + gi * E + u]);
-            GsStages<CLAST, CLAST - 1, 4, ELIM, false>::run(v, tw, tid * G + gi, 2 * LOGR, lc);
+            GsStages<CLAST, CLAST - 1, 4, ELIM, false>::run(v, tw, (sub << (2 * LOGR)) + tid * G + gi, PRE + 2 * LOGR, lc);
 #pragma unroll
             for (int u = 0; u < E; ++u) x[pb0 + gi * E + u] = fold(v[u], lc.q, lc.qinv);
         }
@@ -234,7 +301,7 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         double v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(S * u)];
-        GsStages<LOGR, LOGR - 1, kFolded, ELIM, false>::run(v, tw, bi, LOGR, lc);
+        GsStages<LOGR, LOGR - 1, kFolded, ELIM, false>::run(v, tw, (sub << LOGR) + bi, PRE + LOGR, lc);
 #pragma unroll
         for (int u = 0; u < R; ++u) x[pb + lds_pad_c(S * u)] = fold(v[u], lc.q, lc.qinv);
     }
@@ -244,9 +311,36 @@ __global__ void __launch_bounds__(1 << (LOGN - LOGR), WAVES_PER_EU)
         double v[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) v[u] = x[pb + lds_pad_c(T * u)];
-        GsStages<LOGR, LOGR - 1, kFolded, ELIM, true>::run(v, tw, 0, 0, lc);
+        if constexpr (PRE == 0) {
+            GsStages<LOGR, LOGR - 1, kFolded, ELIM, true>::run(v, tw, 0, 0, lc);
 #pragma unroll
-        for (int u = 0; u < R; ++u) nt_store<NT, uint64_t>(to_residue(v[u], lc.q, lc.qinv), g + tid + T * u);
+            for (int u = 0; u < R; ++u) nt_store<NT, uint64_t>(to_residue(v[u], lc.q, lc.qinv), g + tid + T * u);
+        } else {
+            GsStages<LOGR, LOGR - 1, kFolded, ELIM, false>::run(v, tw, sub, PRE, lc);
+#pragma unroll
+            for (int u = 0; u < R; ++u) nt_store<NT, uint64_t>(f64_raw(fold(v[u], lc.q, lc.qinv)), g + tid + T * u);
+        }
     }
+}
+
+// rings beyond LDS, inverse: the last PRE stages on the strided sets, N^-1 folded into the final one, canonical residues out
+template <int PRE, int ELIM>
+__global__ void __launch_bounds__(256)
+    tail_kernel(uint64_t *__restrict__ data, const TwF *__restrict__ tw_all, const F64Limb *__restrict__ limbs, uint32_t L, uint32_t logN) {
+    constexpr int R = 1 << PRE;
+    const uint32_t S = (1u << logN) >> PRE;
+    const uint32_t sets_blocks = S / blockDim.x;
+    const size_t vec = blockIdx.x / sets_blocks;
+    const uint32_t j = (blockIdx.x - static_cast<uint32_t>(vec) * sets_blocks) * blockDim.x + threadIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const F64Limb lc = limbs[limb];
+    const TwF *tw = tw_all + (static_cast<size_t>(limb) << logN);
+    uint64_t *g = data + (vec << logN) + j;
+    double v[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] = raw_f64(g[static_cast<size_t>(S) * u]);
+    GsStages<PRE, PRE - 1, kFolded, ELIM, true>::run(v, tw, 0, 0, lc);
+#pragma unroll
+    for (int u = 0; u < R; ++u) g[static_cast<size_t>(S) * u] = to_residue(v[u], lc.q, lc.qinv);
 }
 }  // namespace nttf

@@ -91,12 +91,14 @@ def test_ntt_small_rings(gpu, oracle, hip_env, logn, bits):
     assert np.array_equal(g.to_rns(), ev)
 
 
-@pytest.mark.parametrize("bits", [51, 50, 49, 45, 33])
-@pytest.mark.parametrize("logn", [10, 11, 12, 13, 14])
+@pytest.mark.parametrize("logn,bits", [(ln, b) for ln in (10, 11, 12, 13, 14) for b in (51, 50, 49, 45, 33)] +
+                         [(ln, b) for ln in (15, 16, 17) for b in (51, 49, 32)])
 def test_ntt_u64_double_precision_kernels(gpu, oracle, hip_env, logn, bits):
     """64-bit words with moduli below 2^51 take the double-precision transforms (ntt_f64.h: residues as exact integers in
     doubles, products through FMA, folds inserted at compile time so that nothing reaches 2^53 - every second stage at 51
-    bits, once per pass below 2^49): bit-exact against the CPU restatement and against the integer kernels
+    bits, once per pass below 2^49, never inside a pass below 2^40; whole-vector kernels up to 2^14, head / tail + sub-vector
+    kernels at 2^15..2^17 - 32-bit limbs at 2^16 are the default of the reference's Montgomery mod-q tests,
+    tests/test_gpu_ggh15_montgomery_modq_arith.rs:39-40): bit-exact against the CPU restatement and against the integer kernels
     (MXX_HIP_NTT64=int) on random vectors and on the inputs that maximise every intermediate (all q - 1, alternating
     0 / q - 1 at several periods, a spike), both directions, and the decomposition fused into the forward transform."""
     n = 1 << logn

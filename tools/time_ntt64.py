@@ -7,13 +7,13 @@ from mxx_amd import _ffi
 
 lib = _ffi.lib()
 us = mx.GpuDCRTPolyUniformSampler()
-for logn in (10, 11, 12, 13, 14):
+for logn, bits in ((10, 51), (11, 51), (12, 51), (13, 51), (14, 51), (15, 51), (16, 51), (17, 51), (16, 32), (14, 32)):
     n = 1 << logn
-    p = mx.GpuDCRTPolyParams(n, mx.gen_crt_basis(n, 4, 51), 17)
+    p = mx.GpuDCRTPolyParams(n, mx.gen_crt_basis(n, 4, bits), 16)
     ctx = p.ctx()
-    for polys in (64, 4096):
+    for polys in ((64, 4096) if logn <= 14 else (64, 512)):
         m = us.sample_uniform(p, polys, 1, mx.DistType.FinRingDist())
-        line = f"51-bit n=2^{logn} polys={polys:5d}:"
+        line = f"{bits}-bit n=2^{logn} polys={polys:5d}:"
         for mode in ("int", "f64"):
             if mode == "int":
                 os.environ["MXX_HIP_NTT64"] = "int"
