@@ -6,16 +6,23 @@
 // cuda/src/matrix/MatrixTrapdoor.cu:234-241,772-779):
 //   subkey  = HChaCha20(key = seed words (LE), nonce = domain_tag || stream2)
 //   state   = "expand 32-byte k" | subkey | counter32 = 0 | nonce96 = (stream0, stream1)
-//   output  = successive ChaCha20 blocks (32-bit block counter), read as 8 LE u64 words each.
-// One departure from the reference, deliberate: ChaCha.cu:138-149 puts stream0 into the block
-// counter words, so block b of stream (s0, s1) is block 0 of stream (s0 + b, s1) - and stream ids
-// are consecutive everywhere (poly+1, column+1, tower+1), i.e. neighbouring polynomials, columns
-// and towers would share keystream one block apart.  Here the counter is a pure block counter and
-// the stream words live in the 96-bit nonce (RFC 8439 layout): stream0 in words 13 and 15[0:16],
-// stream1 in words 14 and 15[16:32] (48 bits each; every stream id on this path is a polynomial,
-// column, tower or coefficient index + 1).  No reference test pins keystream bytes; the
-// properties callers rely on (pure function of (seed, global index), column windows commute,
-// src/sampler/gpu.rs:292-361) are unchanged.
+//   output  = successive ChaCha20 blocks (32-bit block counter).
+// Departures from the reference, deliberate (no reference test pins keystream bytes; the properties callers rely
+// on - pure function of (seed, global index), column windows commute, src/sampler/gpu.rs:292-361 - are unchanged):
+//  1. ChaCha.cu:138-149 puts stream0 into the block counter words, so block b of stream (s0, s1) is block 0 of
+//     stream (s0 + b, s1) - and stream ids are consecutive everywhere (poly+1, column+1, tower+1), i.e. neighbouring
+//     polynomials, columns and towers would share keystream one block apart.  Here the counter is a pure block
+//     counter and the stream words live in the 96-bit nonce (RFC 8439 layout): stream0 in words 13 and 15[0:16],
+//     stream1 in words 14 and 15[16:32] (48 bits each).
+//  2. uniform / bit / ternary: eight fixed-position draws per block (sampling.hip).
+//  3. (round 3) The Gaussian samplers read the keystream as little-endian 16-BIT DRAWS, 32 per block.  Karney's
+//     uniform deviates are only ever compared, so a deviate is drawn lazily: m 2^-53 with m = max(hi 2^37 + lo, 1),
+//     hi = one draw, lo (37 bits = three more draws) only when a comparison ties on hi (one comparison in 65536) -
+//     first the threshold's lo if the threshold is itself a deviate whose lo is still undrawn, then the deviate's.
+//     Every comparison is the one the reference makes on 53-bit deviates; the keystream per integer drops from ~19
+//     64-bit words to ~21 draws, i.e. from 2.4 blocks to 0.65.  A 64-bit word (Box-Muller, the offset j of a trial) is
+//     four consecutive draws.  The G-sampler's streams are keyed under ONE sub-key per call (coefficient index moved
+//     from stream2 into stream0), so no kernel on this path carries a per-lane key.
 // Discrete Gaussians use Karney's exact rejection sampler with the reference's
 // iteration caps (cuda/src/matrix/MatrixSampling.cu:30-147): only IEEE double
 // compare / add / mul / div / ceil are involved, so the CPU oracle reproduces the
@@ -24,12 +31,12 @@
 // Wave64 shape of the sampler.  A rejection sampler written as nested data-dependent
 // loops makes a wave pay the product of the per-level maxima over its 64 lanes, and a
 // ChaCha block refill inside such loops is executed once per straggling lane.  Here
-//   * every lane owns a 16-word ring of keystream in LDS; blocks are generated only at
-//     explicit, wave-convergent checkpoints (rng_fill), one per 8 draws at most;
-//   * Karney's algorithm is a flat state machine that consumes exactly one keystream
-//     word per step, so all lanes of a wave sit at the same program point and a wave
-//     pays max-over-lanes of the TOTAL draw count once.
-// The sequence of draws and decisions per lane is unchanged (bit-identical samples).
+//   * every lane owns a ring of 64 draws (two blocks) in LDS; blocks are generated only at explicit,
+//     wave-convergent checkpoints (rng_fill_wave): when few lanes are short, FOUR LANES COMPUTE ONE BLOCK (a
+//     column of the state each, the diagonal rounds through DPP quad permutes), 16 blocks per pass of ~330
+//     instructions for whichever lanes asked; when most are, every lane computes its own;
+//   * Karney's algorithm is a flat state machine that consumes exactly one draw per step, so all lanes of a wave
+//     sit at the same program point and a wave pays max-over-lanes of the TOTAL draw count once.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -40,15 +47,15 @@
 
 struct ChaChaRng {
     uint32_t state[16];
-    uint64_t *ring;    // this lane's ring: element s lives at ring[s * ring_stride]
+    uint32_t *ring;    // this lane's ring: 32-bit slot s (draws 2s, 2s+1) lives at ring[s * ring_stride]
     uint32_t ring_stride;
-    uint32_t head;     // words consumed
-    uint32_t tail;     // words generated
+    uint32_t head;     // draws consumed
+    uint32_t tail;     // draws generated (a multiple of 32: blocks land in one half of the ring or the other)
 };
 
-// LDS bytes a block of `threads` lanes needs for its rings
-#define RNG_RING_WORDS 16
-#define RNG_LDS_BYTES(threads) ((threads) * RNG_RING_WORDS * sizeof(uint64_t))
+// a lane's ring: 32 slots of 32 bits = 64 draws = two keystream blocks (128 bytes, 32 KB per 256 lanes)
+#define RNG_RING_SLOTS 32
+#define RNG_BLOCK_DRAWS 32u
 
 __host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
@@ -126,7 +133,7 @@ __host__ __device__ __forceinline__ void chacha_block_words(const ChaChaKey &key
         out[i] = static_cast<uint64_t>(x[2 * i] + st[2 * i]) | (static_cast<uint64_t>(x[2 * i + 1] + st[2 * i + 1]) << 32);
 }
 
-__device__ __forceinline__ void rng_init_keyed(ChaChaRng &rng, uint64_t *ring_base, const ChaChaKey &key,
+__device__ __forceinline__ void rng_init_keyed(ChaChaRng &rng, uint32_t *ring_base, const ChaChaKey &key,
                                                uint64_t stream0, uint64_t stream1) {
     rng.state[0] = 0x61707865u; rng.state[1] = 0x3320646eu; rng.state[2] = 0x79622d32u; rng.state[3] = 0x6b206574u;
 #pragma unroll
@@ -138,13 +145,13 @@ __device__ __forceinline__ void rng_init_keyed(ChaChaRng &rng, uint64_t *ring_ba
     rng.tail = 0;
 }
 
-__device__ __forceinline__ void rng_init(ChaChaRng &rng, uint64_t *ring_base, const GpuRngSeed &seed, uint64_t stream0,
+__device__ __forceinline__ void rng_init(ChaChaRng &rng, uint32_t *ring_base, const GpuRngSeed &seed, uint64_t stream0,
                                          uint64_t stream1, uint64_t stream2, uint64_t domain_tag) {
     rng_init_keyed(rng, ring_base, chacha_subkey(seed, stream2, domain_tag), stream0, stream1);
 }
 
 // Re-key an open generator to another stream of the same family, positioned at keystream block
-// `block`; buffered words are dropped
+// `block`; buffered draws are dropped
 __device__ __forceinline__ void rng_reopen(ChaChaRng &rng, uint64_t stream0, uint64_t stream1, uint32_t block = 0) {
     chacha_set_stream(rng.state, stream0, stream1, block);
     rng.head = rng.tail;
@@ -152,29 +159,122 @@ __device__ __forceinline__ void rng_reopen(ChaChaRng &rng, uint64_t stream0, uin
 
 __device__ __forceinline__ uint32_t rng_avail(const ChaChaRng &rng) { return rng.tail - rng.head; }
 
-// Checkpoint: guarantees >= 8 words are available.  Call at wave-convergent points, at least
-// once per 8 draws.
+// this lane computes the next block of its own stream into the free half of its ring (needs avail <= 32)
 template <int UNROLL = 1>
-__device__ __forceinline__ void rng_fill(ChaChaRng &rng) {
-    if (rng.tail - rng.head < 8) {
-        uint32_t x[16];
+__device__ __forceinline__ void rng_block_lane(ChaChaRng &rng) {
+    uint32_t x[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = rng.state[i];
-        chacha_rounds<UNROLL>(x);
+    for (int i = 0; i < 16; ++i) x[i] = rng.state[i];
+    chacha_rounds<UNROLL>(x);
+    const uint32_t slot0 = (rng.tail >> 1) & (RNG_RING_SLOTS - 1);  // 0 or 16
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t lo = x[2 * i] + rng.state[2 * i], hi = x[2 * i + 1] + rng.state[2 * i + 1];
-            rng.ring[((rng.tail + i) & (RNG_RING_WORDS - 1)) * rng.ring_stride] =
-                static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
-        }
-        ++rng.state[12];  // 2^32 blocks = 256 GiB per stream; no stream on this path draws more than a few
-        rng.tail += 8;
-    }
+    for (int i = 0; i < 16; ++i) rng.ring[(slot0 + i) * rng.ring_stride] = x[i] + rng.state[i];
+    ++rng.state[12];  // 2^32 blocks = 256 GiB per stream; no stream on this path draws more than a few
+    rng.tail += RNG_BLOCK_DRAWS;
 }
 
-__device__ __forceinline__ uint64_t rng_next_u64(ChaChaRng &rng) {
-    const uint64_t v = rng.ring[(rng.head & (RNG_RING_WORDS - 1)) * rng.ring_stride];
+// Per-lane checkpoint (divergent callers: the one-thread-per-element kernels): afterwards at least 32 draws are
+// available.  Call at least once per 8 state-machine steps (a step takes one draw, a service point at most six).
+template <int UNROLL = 1>
+__device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
+    if (rng.tail - rng.head <= RNG_BLOCK_DRAWS) rng_block_lane<UNROLL>(rng);
+}
+
+// dpp quad permutes: lane c of every quad reads lane (c + 1) & 3 / (c + 2) & 3 / (c + 3) & 3 of its quad
+#define RNG_QUAD_ROT1(v) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x39, 0xf, 0xf, false))
+#define RNG_QUAD_ROT2(v) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4e, 0xf, 0xf, false))
+#define RNG_QUAD_ROT3(v) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x93, 0xf, 0xf, false))
+#define RNG_QUAD_LANE0(v) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x00, 0xf, 0xf, false))
+
+// Wave-convergent checkpoint of the persistent-lane kernels: EVERY lane of the wave calls it (idle lanes with
+// live = false); call once per 8 steps.  A live lane with room for a block (at most 32 draws left) "wants" one; it
+// is "urgent" from 20 draws down (8 steps + two service points take at most 19) and "starving" below 6.
+// Policy (MXX_FILL_POLICY, compile time; profiles/r03_notes.md has the A/B):
+//   a pass happens when the checkpoint is `scheduled` and some lane is urgent, or when 16 lanes are starving;
+//   in a pass every wanting lane computes its own block (960 instructions for up to 64 blocks).
+// MXX_FILL_POLICY == 1 adds the cooperative form for passes with fewer than 40 wanting lanes: the first 16 get a quad
+// each; lane c of the quad holds column c of the requester's state (its counter / nonce words fetched with
+// ds_bpermute, key and constants are uniform), column rounds in place, diagonal rounds with rows b, c, d rotated by
+// 1, 2, 3 lanes through DPP, and writes its four output words into the requester's ring (same bytes either way;
+// the key words rng.state[0..11] must be wave-uniform).
+#ifndef MXX_FILL_POLICY
+#define MXX_FILL_POLICY 0
+#endif
+__device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool scheduled = true) {
+#if MXX_FILL_POLICY == 0
+    const uint32_t avail = rng.tail - rng.head;
+    const bool pass = (scheduled && __any(live && avail <= 20u)) || __popcll(__ballot(live && avail < 6u)) >= 16;
+    if (pass && live && avail <= RNG_BLOCK_DRAWS) rng_block_lane<10>(rng);
+#else
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t col = lane & 3u;
+    for (;;) {
+        const uint32_t avail = rng.tail - rng.head;
+        const bool want = live && avail <= RNG_BLOCK_DRAWS;
+        const uint64_t mw = __ballot(want);
+        const uint32_t n = static_cast<uint32_t>(__popcll(mw));
+        if (n == 0) break;
+        if (n >= 40) {
+            if (want) rng_block_lane<10>(rng);
+            break;
+        }
+        if (n < 16 && !__any(live && avail <= 20u)) break;
+        // requester with rank r < 16 announces itself to lane 4r (everyone else writes to an odd lane nobody reads)
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mw >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mw), 0u));
+        const bool served = want && rank < 16u;
+        const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>((served ? rank * 4u : (lane | 1u)) * 4u), static_cast<int>(lane + 1u)));
+        const uint32_t req1 = RNG_QUAD_LANE0(got);  // requester's lane + 1, 0: this quad has no work
+        const uint32_t req = req1 ? req1 - 1u : lane;
+        const int src = static_cast<int>(req * 4u);
+        const uint32_t s12 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(rng.state[12])));
+        const uint32_t s13 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(rng.state[13])));
+        const uint32_t s14 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(rng.state[14])));
+        const uint32_t s15 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(rng.state[15])));
+        const uint32_t rtail = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(rng.tail)));
+        const uint32_t a0 = col == 0 ? rng.state[0] : col == 1 ? rng.state[1] : col == 2 ? rng.state[2] : rng.state[3];
+        const uint32_t b0 = col == 0 ? rng.state[4] : col == 1 ? rng.state[5] : col == 2 ? rng.state[6] : rng.state[7];
+        const uint32_t c0 = col == 0 ? rng.state[8] : col == 1 ? rng.state[9] : col == 2 ? rng.state[10] : rng.state[11];
+        const uint32_t d0 = col == 0 ? s12 : col == 1 ? s13 : col == 2 ? s14 : s15;
+        uint32_t a = a0, b = b0, c = c0, d = d0;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            CHACHA_QR(a, b, c, d)
+            b = RNG_QUAD_ROT1(b); c = RNG_QUAD_ROT2(c); d = RNG_QUAD_ROT3(d);
+            CHACHA_QR(a, b, c, d)
+            b = RNG_QUAD_ROT3(b); c = RNG_QUAD_ROT2(c); d = RNG_QUAD_ROT1(d);
+        }
+        if (req1) {
+            uint32_t *dst = rng.ring + (static_cast<int>(req) - static_cast<int>(lane));  // the requester's ring (same wave)
+            const uint32_t slot0 = ((rtail >> 1) & (RNG_RING_SLOTS - 1)) + col;
+            dst[slot0 * rng.ring_stride] = a + a0;
+            dst[(slot0 + 4u) * rng.ring_stride] = b + b0;
+            dst[(slot0 + 8u) * rng.ring_stride] = c + c0;
+            dst[(slot0 + 12u) * rng.ring_stride] = d + d0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (served) {
+            ++rng.state[12];
+            rng.tail += RNG_BLOCK_DRAWS;
+        }
+    }
+#endif
+}
+
+// one 16-bit draw (the caller has checked rng_avail)
+__device__ __forceinline__ uint32_t rng_next16(ChaChaRng &rng) {
+    const uint32_t w = rng.ring[((rng.head >> 1) & (RNG_RING_SLOTS - 1)) * rng.ring_stride];
+    const uint32_t v = (rng.head & 1u) ? (w >> 16) : (w & 0xffffu);
     ++rng.head;
+    return v;
+}
+
+// four draws, little-endian
+__device__ __forceinline__ uint64_t rng_next_u64(ChaChaRng &rng) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v |= static_cast<uint64_t>(rng_next16(rng)) << (16 * i);
     return v;
 }
 
@@ -221,196 +321,50 @@ __device__ __forceinline__ double rng_standard_normal(ChaChaRng &rng) {
     return sqrt(-2.0 * det_log(u1)) * det_cos2pi(u2);
 }
 
-__device__ __forceinline__ uint64_t rng_uniform_mod(ChaChaRng &rng, uint64_t q) {
-    const uint64_t max = ~0ull;
-    const uint64_t threshold = max - (max % q);
-    for (uint32_t step = 0;; ++step) {
-        if ((step & 7) == 0) rng_fill(rng);
-        uint64_t x = rng_next_u64(rng);
-        if (x < threshold) return x % q;
-    }
-}
-
 // ---- Karney's exact discrete Gaussian (algorithm D of arXiv:1303.6257) as a state machine --
-// One keystream word per step.  Sequential form it reproduces, draw for draw:
-//   trial: k = G();  if !P(k(k-1)) retry;  s = bit;  j = word % ceil(sigma);  x = ...;
+// One draw per step.  Sequential form it reproduces, draw for draw (U = a lazy deviate, see the header):
+//   trial: k = G();  if !P(k(k-1)) retry;  s = draw & 1;  j = (four draws as a u64) % ceil(sigma);  x = ...;
 //          if x out of range retry;  (k+1) times B(k,x) must hold, else retry;  return s(i0+j)
 //   H (prob e^-1/2): a=U; if !(a<1/2) true; loop { b=U; if !(b<a) false; a=U; if !(a<b) true }
 //   G: count consecutive H successes (cap 1024);  P(n): n consecutive H successes
 //   B(k,x): y=x,n=0; loop { z=U; if !(z<y) stop; r=U; if !(r<(2k+x)/(2k+2)) stop; y=z; if n>4096 stop; ++n }
 //           result = n even
-static __device__ int64_t sample_integer_karney(ChaChaRng &rng, double mean, double stddev) {
-    if (!(stddev > 0.0) || !isfinite(mean) || !isfinite(stddev)) return static_cast<int64_t>(llround(mean));
-    const int64_t ceil_std = static_cast<int64_t>(ceil(stddev));
-    if (ceil_std <= 0) return static_cast<int64_t>(llround(mean));
-
-    enum { ST_H0 = 0, ST_H1, ST_H2, ST_SIGN, ST_J, ST_B0, ST_B1 };
-    int st = ST_H0;
-    bool in_p = false;       // H outcomes feed P (true) or G (false)
-    int32_t k = 0;           // G's count
-    int32_t p_left = 0;      // H successes P still needs
-    int32_t b_left = 0;      // B successes still needed
-    int32_t bn = 0;          // B's step parity counter
-    double ha = 0.0, hb = 0.0, x = 0.0, x0 = 0.0, y = 0.0, zz = 0.0, bthr = 0.0;
-    int64_t s = 1, i0 = 0, j = 0, result = 0;
-    int iter = 0;
-    bool done = false, fallback = false;
-
-    for (uint32_t step = 0; !done; ++step) {
-        if ((step & 7) == 0) rng_fill(rng);
-        const uint64_t w = rng_next_u64(rng);
-        const double u = u64_to_open01(w);
-        int hres = -1;      // outcome of H finished this step
-        int bres = -1;      // outcome of B finished this step
-        bool restart = false;
-        switch (st) {
-            case ST_H0:
-                ha = u;
-                if (!(ha < 0.5)) hres = 1; else st = ST_H1;
-                break;
-            case ST_H1:
-                hb = u;
-                if (!(hb < ha)) hres = 0; else st = ST_H2;
-                break;
-            case ST_H2:
-                ha = u;
-                if (!(ha < hb)) hres = 1; else st = ST_H1;
-                break;
-            case ST_SIGN: {
-                s = (w & 1ull) ? 1 : -1;
-                const double di0 = stddev * static_cast<double>(k) + static_cast<double>(s) * mean;
-                i0 = static_cast<int64_t>(ceil(di0));
-                x0 = (static_cast<double>(i0) - di0) / stddev;
-                st = ST_J;
-                break;
-            }
-            case ST_J:
-                j = static_cast<int64_t>(w % static_cast<uint64_t>(ceil_std));
-                x = x0 + static_cast<double>(j) / stddev;
-                if (!(x < 1.0) || (x == 0.0 && s < 0 && k == 0)) {
-                    restart = true;
-                } else {
-                    b_left = k + 1;
-                    bthr = (2.0 * static_cast<double>(k) + x) / static_cast<double>(2 * k + 2);
-                    y = x;
-                    bn = 0;
-                    st = ST_B0;
-                }
-                break;
-            case ST_B0:
-                zz = u;
-                if (!(zz < y)) bres = (bn % 2) == 0; else st = ST_B1;
-                break;
-            default:  // ST_B1
-                if (!(u < bthr)) {
-                    bres = (bn % 2) == 0;
-                } else {
-                    y = zz;
-                    if (bn > 4096) bres = (bn % 2) == 0;
-                    else { ++bn; st = ST_B0; }
-                }
-                break;
-        }
-        if (hres >= 0) {
-            if (!in_p) {  // G: count successes
-                bool g_done = hres == 0;
-                if (hres == 1) {
-                    ++k;
-                    if (k > 1024) g_done = true;
-                }
-                if (g_done) {
-                    p_left = k * (k - 1);
-                    if (p_left == 0) st = ST_SIGN;
-                    else { in_p = true; st = ST_H0; }
-                } else {
-                    st = ST_H0;
-                }
-            } else {  // P: needs p_left successes
-                if (hres == 1) {
-                    if (--p_left == 0) st = ST_SIGN; else st = ST_H0;
-                } else {
-                    restart = true;
-                }
-            }
-        }
-        if (bres >= 0) {
-            if (bres == 1) {
-                if (--b_left == 0) {
-                    result = s * (i0 + j);
-                    done = true;
-                } else {
-                    y = x;
-                    bn = 0;
-                    st = ST_B0;
-                }
-            } else {
-                restart = true;
-            }
-        }
-        if (restart) {
-            if (++iter >= (1 << 16)) {
-                fallback = true;
-                done = true;
-            } else {
-                k = 0;
-                in_p = false;
-                st = ST_H0;
-            }
-        }
-    }
-    if (fallback) {
-        rng_fill(rng);
-        result = static_cast<int64_t>(llround(mean + stddev * rng_standard_normal(rng)));
-    }
-    return result;
-}
-
-
-// Elements per workgroup chunk for the persistent-lane kernels: one resident round of the whole
-// chip when the problem is big enough (chunks are consumed dynamically inside a workgroup, so the
-// only imbalance left is the last element of each lane).  MXX_HIP_SAMPLER_PER_LANE=n forces n
-// elements per lane (tests use it to exercise stream switching at small sizes).
-static inline uint32_t sampler_per_lane(size_t total, const void *kernel, int device, int forced) {
-    if (forced >= 1) return static_cast<uint32_t>(forced);
-    int blocks_per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) != hipSuccess || blocks_per_cu < 1)
-        blocks_per_cu = 2;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
-    const size_t lanes = static_cast<size_t>(blocks_per_cu) * cus * 256u;
-    const size_t per = (total + lanes - 1) / lanes;
-    return static_cast<uint32_t>(per < 1 ? 1 : (per > 4096 ? 4096 : per));
-}
-
-// ---- Persistent-lane form of the same sampler ---------------------------------------------------
-// A lane works through a list of coefficients; the wave steps all lanes together:
-//   every step      : lanes in the cheap states (H*, B*) consume one keystream word;
-//   every 4th step  : the expensive transitions (sign + offset draw with its three divisions
-//                     and the 64-bit modulo, the normal fallback, and the caller's
-//                     "sample finished" action) run for the lanes parked in them;
-//   every 8th step  : keystream refill (all live lanes together).
-// A lane only consumes words it holds (rng_avail), so the per-stream draw order - and therefore
-// every sample - is that of sample_integer_karney above.  A wave now pays max-over-lanes of the
-// SUM of the draw counts of its lanes' coefficients (which concentrates around the mean) instead
-// of the per-coefficient maximum, and the expensive code runs a quarter as often.
+//
+// Persistent-lane form.  A lane works through a list of coefficients; the wave steps all lanes together:
+//   every step      : lanes in the cheap states (H, B0, B1) consume one draw;
+//   every 4th step  : the expensive transitions (sign + offset draw with its three divisions and the 64-bit
+//                     modulo, a tied comparison's low bits, the normal fallback, and the caller's "sample
+//                     finished" action) run for the lanes parked in them;
+//   every 8th step  : keystream refill (rng_fill_wave).
+// A lane only consumes draws it holds (rng_avail), so the per-stream draw order - and therefore every sample - is
+// that of the sequential form.  A wave pays max-over-lanes of the SUM of the draw counts of its lanes' coefficients
+// (which concentrates around the mean) instead of the per-coefficient maximum.
 // Cheap states all have the shape "draw u; continue while u < T":
-//   H (Bernoulli e^-1/2): T starts at 1/2 and becomes the last draw; the outcome is the parity
-//      of the run length (the H0/H1/H2 states of the sequential form collapse into T + parity);
+//   H (Bernoulli e^-1/2): T starts at 1/2 and becomes the last draw; the outcome is the parity of the run length;
 //   B0: T = y, B1: T = (2k+x)/(2k+2) - the two alternating comparisons of B(k, x).
-// Every uniform is m * 2^-53 with the integer m = max(word >> 11, 1), so "u < T" is decided
-// exactly on integers: m < ceil(T * 2^53) (scaling by 2^53 is exact).  The cheap path is
-// therefore integer-only; doubles appear in the expensive transitions alone.
-enum { KS_H = 0, KS_B0, KS_B1, KS_SIGN, KS_FALLBACK, KS_DONE, KS_IDLE };
+// A threshold is ceil(T 2^53) split as (hi = top 16 bits, up to 65536 for T = 1; lo = 37 bits); the cheap path
+// compares the draw with hi alone and parks the lane in KS_TIE when they are equal.  T_tag says where T's lo lives
+// if it is ever needed: a constant (1/2, x, (2k+x)/(2k+2)), a deviate whose lo was drawn in an earlier tie (T_lo, or
+// zz_lo for y = z), or a deviate whose lo is still undrawn.
+enum { KS_H = 0, KS_B0, KS_B1, KS_SIGN, KS_TIE, KS_FALLBACK, KS_DONE, KS_IDLE };
+enum { KT_UNDRAWN = 0, KT_HALF, KT_XT, KT_BT, KT_ZZ, KT_OWN };
 
 struct KarneyFsm {
     int32_t st, k, p_left, b_left, bn, iter, par;
     bool in_p;
-    uint64_t T, xt, bt, zz;  // thresholds / last draw in units of 2^-53: current, x, (2k+x)/(2k+2), z
+    uint32_t T_hi, T_tag;      // current threshold
+    uint32_t zz_hi, zz_tag;    // B's last z (KT_UNDRAWN or KT_OWN)
+    uint32_t xt_hi, bt_hi;     // x and (2k+x)/(2k+2) in ticks of 2^-53, top parts
+    uint32_t tie_h, tie_st;    // the draw that tied and the state it tied in
+    uint64_t T_lo, zz_lo, xt_lo, bt_lo;
     double mean, stddev;
     uint64_t cs, magic;  // ceil(stddev) and floor((2^64-1)/cs)
     int64_t result;
 };
 
-#define KARNEY_HALF (1ull << 52)
+#define KARNEY_LO_BITS 37
+#define KARNEY_LO_MASK ((1ull << KARNEY_LO_BITS) - 1)
+#define KARNEY_HALF_HI (1u << 15)
 
 // t in [0, 1] -> ceil(t * 2^53)
 __device__ __forceinline__ uint64_t karney_ticks(double t) { return static_cast<uint64_t>(ceil(t * 9007199254740992.0)); }
@@ -431,6 +385,19 @@ __host__ __device__ __forceinline__ KarneyDivisor karney_divisor(double stddev) 
     return d;
 }
 
+// once per lane, before the first karney_begin (the select-style transitions read every field)
+__device__ __forceinline__ void karney_reset(KarneyFsm &f) {
+    f.st = KS_DONE;
+    f.k = f.p_left = f.b_left = f.bn = f.iter = f.par = 0;
+    f.in_p = false;
+    f.T_hi = f.T_tag = f.zz_hi = f.zz_tag = f.xt_hi = f.bt_hi = f.tie_h = f.tie_st = 0;
+    f.T_lo = f.zz_lo = f.xt_lo = f.bt_lo = 0;
+    f.mean = f.stddev = 0.0;
+    f.cs = 1;
+    f.magic = 0;
+    f.result = 0;
+}
+
 __device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double stddev, const KarneyDivisor &d) {
     f.mean = mean;
     f.stddev = stddev;
@@ -442,24 +409,33 @@ __device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double s
     f.cs = d.cs;
     f.magic = d.magic;
     f.st = KS_H;
-    f.T = KARNEY_HALF;
+    f.T_hi = KARNEY_HALF_HI;
+    f.T_tag = KT_HALF;
     f.par = 0;
     f.k = 0;
     f.in_p = false;
     f.iter = 0;
 }
 
-// one cheap step
-__device__ __forceinline__ void karney_light(KarneyFsm &f, ChaChaRng &rng) {
-    if (f.st > KS_B1 || rng_avail(rng) == 0) return;
-    uint64_t m = rng_next_u64(rng) >> 11;
-    m = m ? m : 1;  // u64_to_open01's clamp away from 0 (m < 2^53 always)
+// the transition after a comparison "draw < T" came out as `lt`; h = the draw's top 16 bits, lo = its low 37 bits
+// when they were drawn (KNOWN: the comparison tied)
+template <bool KNOWN>
+__device__ __forceinline__ void karney_advance(KarneyFsm &f, bool lt, uint32_t h, uint64_t lo) {
     const bool is_h = f.st == KS_H, is_b0 = f.st == KS_B0, is_b1 = f.st == KS_B1;
     // B's step cap (n > 4096) ends the run as a failed comparison would
-    const bool cont = (m < f.T) && !(is_b1 && f.bn > 4096);
-    f.zz = is_b0 ? m : f.zz;
+    const bool cont = lt && !(is_b1 && f.bn > 4096);
+    const uint32_t own = KNOWN ? KT_OWN : KT_UNDRAWN;
+    const uint32_t prev_zz_hi = f.zz_hi, prev_zz_tag = f.zz_tag;
+    f.zz_hi = is_b0 ? h : f.zz_hi;
+    f.zz_tag = is_b0 ? own : f.zz_tag;
+    if (KNOWN) {
+        f.zz_lo = is_b0 ? lo : f.zz_lo;
+        f.T_lo = is_h ? lo : f.T_lo;
+    }
     if (cont) {
-        f.T = is_h ? m : (is_b0 ? f.bt : f.zz);
+        // H: T = this draw;  B0: T = (2k+x)/(2k+2);  B1: T = y = z
+        f.T_hi = is_h ? h : (is_b0 ? f.bt_hi : prev_zz_hi);
+        f.T_tag = is_h ? own : (is_b0 ? static_cast<uint32_t>(KT_BT) : (prev_zz_tag == KT_OWN ? static_cast<uint32_t>(KT_ZZ) : static_cast<uint32_t>(KT_UNDRAWN)));
         f.par ^= is_h ? 1 : 0;
         f.bn += is_b1 ? 1 : 0;
         f.st = is_h ? KS_H : (is_b0 ? KS_B1 : KS_B0);
@@ -498,16 +474,39 @@ __device__ __forceinline__ void karney_light(KarneyFsm &f, ChaChaRng &rng) {
         next = it >= (1 << 16) ? KS_FALLBACK : KS_H;
     }
     f.st = next;
-    f.T = next == KS_H ? KARNEY_HALF : f.xt;  // a fresh H run, or B(k, x) starting over with y = x
+    // a fresh H run, or B(k, x) starting over with y = x
+    f.T_hi = next == KS_H ? KARNEY_HALF_HI : f.xt_hi;
+    f.T_tag = next == KS_H ? KT_HALF : KT_XT;
     f.par = 0;
     f.bn = 0;
 }
 
+// one cheap step
+__device__ __forceinline__ void karney_light(KarneyFsm &f, ChaChaRng &rng) {
+    if (f.st > KS_B1 || rng_avail(rng) == 0) return;
+    const uint32_t h = rng_next16(rng);
+    if (h == f.T_hi) {  // one comparison in 65536: the low bits decide, at the next service point
+        f.tie_h = h;
+        f.tie_st = static_cast<uint32_t>(f.st);
+        f.st = KS_TIE;
+        return;
+    }
+    karney_advance<false>(f, h < f.T_hi, h, 0);
+}
+
+// the 37 low bits of a deviate: three draws
+__device__ __forceinline__ uint64_t karney_draw_lo(ChaChaRng &rng, uint32_t hi) {
+    const uint64_t d1 = rng_next16(rng), d2 = rng_next16(rng), d3 = rng_next16(rng);
+    const uint64_t lo = (d1 << 21) | (d2 << 5) | (d3 >> 11);
+    return (hi == 0 && lo == 0) ? 1 : lo;  // a deviate is never 0
+}
+
 // the expensive transitions; call at wave-convergent service points
 __device__ __forceinline__ void karney_heavy(KarneyFsm &f, ChaChaRng &rng) {
-    if (f.st == KS_SIGN && rng_avail(rng) >= 2) {
-        const uint64_t w1 = rng_next_u64(rng), w2 = rng_next_u64(rng);
-        const int64_t s = (w1 & 1ull) ? 1 : -1;
+    if (f.st == KS_SIGN && rng_avail(rng) >= 5) {
+        const uint32_t w1 = rng_next16(rng);
+        const uint64_t w2 = rng_next_u64(rng);
+        const int64_t s = (w1 & 1u) ? 1 : -1;
         const double di0 = f.stddev * static_cast<double>(f.k) + static_cast<double>(s) * f.mean;
         const int64_t i0 = static_cast<int64_t>(ceil(di0));
         const double x0 = (static_cast<double>(i0) - di0) / f.stddev;
@@ -520,19 +519,68 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, ChaChaRng &rng) {
             f.k = 0;
             f.in_p = false;
             f.st = it >= (1 << 16) ? KS_FALLBACK : KS_H;
-            f.T = KARNEY_HALF;
+            f.T_hi = KARNEY_HALF_HI;
+            f.T_tag = KT_HALF;
             f.par = 0;
         } else {
             f.b_left = f.k + 1;
-            f.xt = karney_ticks(x);
-            f.bt = karney_ticks((2.0 * static_cast<double>(f.k) + x) / static_cast<double>(2 * f.k + 2));
-            f.T = f.xt;
+            const uint64_t xt = karney_ticks(x);
+            const uint64_t bt = karney_ticks((2.0 * static_cast<double>(f.k) + x) / static_cast<double>(2 * f.k + 2));
+            f.xt_hi = static_cast<uint32_t>(xt >> KARNEY_LO_BITS);
+            f.xt_lo = xt & KARNEY_LO_MASK;
+            f.bt_hi = static_cast<uint32_t>(bt >> KARNEY_LO_BITS);
+            f.bt_lo = bt & KARNEY_LO_MASK;
+            f.T_hi = f.xt_hi;
+            f.T_tag = KT_XT;
             f.bn = 0;
             f.result = s * (i0 + static_cast<int64_t>(j));
             f.st = KS_B0;
         }
-    } else if (f.st == KS_FALLBACK && rng_avail(rng) >= 2) {
+    } else if (f.st == KS_TIE && rng_avail(rng) >= 6) {
+        // the threshold's low bits first (drawn now if it is a deviate that never needed them), then the deviate's
+        uint64_t tlo;
+        switch (f.T_tag) {
+            case KT_HALF: tlo = 0; break;
+            case KT_XT: tlo = f.xt_lo; break;
+            case KT_BT: tlo = f.bt_lo; break;
+            case KT_ZZ: tlo = f.zz_lo; break;
+            case KT_OWN: tlo = f.T_lo; break;
+            default: tlo = karney_draw_lo(rng, f.T_hi); break;
+        }
+        const uint64_t ulo = karney_draw_lo(rng, f.tie_h);
+        f.st = static_cast<int32_t>(f.tie_st);
+        karney_advance<true>(f, ulo < tlo, f.tie_h, ulo);
+    } else if (f.st == KS_FALLBACK && rng_avail(rng) >= 8) {
         f.result = static_cast<int64_t>(llround(f.mean + f.stddev * rng_standard_normal(rng)));
         f.st = KS_DONE;
     }
 }
+
+// the same machine run by one lane on its own (the one-thread-per-element kernels)
+static __device__ int64_t sample_integer_karney(ChaChaRng &rng, double mean, double stddev) {
+    KarneyFsm f;
+    karney_reset(f);
+    karney_begin(f, mean, stddev, karney_divisor(stddev));
+    for (uint32_t step = 0; f.st != KS_DONE; ++step) {
+        if ((step & 7) == 0) rng_fill_lane(rng);
+        karney_heavy(f, rng);
+        karney_light(f, rng);
+    }
+    return f.result;
+}
+
+// Elements per workgroup chunk for the persistent-lane kernels: one resident round of the whole
+// chip when the problem is big enough (chunks are consumed dynamically inside a workgroup, so the
+// only imbalance left is the last element of each lane).  MXX_HIP_SAMPLER_PER_LANE=n forces n
+// elements per lane (tests use it to exercise stream switching at small sizes).
+static inline uint32_t sampler_per_lane(size_t total, const void *kernel, int device, int forced) {
+    if (forced >= 1) return static_cast<uint32_t>(forced);
+    int blocks_per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) != hipSuccess || blocks_per_cu < 1)
+        blocks_per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    const size_t lanes = static_cast<size_t>(blocks_per_cu) * cus * 256u;
+    const size_t per = (total + lanes - 1) / lanes;
+    return static_cast<uint32_t>(per < 1 ? 1 : (per > 4096 ? 4096 : per));
+}
+

@@ -7,7 +7,7 @@
 // sample_distribution_columns therefore equals the matching column slice of the full
 // sample for the same seed (reference: MatrixSampling.cu:232-289, test
 // src/sampler/gpu.rs:323-361).  Gaussian: a ChaCha20 stream per coefficient (Karney's
-// sampler draws a variable number of words).  Uniform / bit / ternary: fixed-position
+// sampler takes a variable number of 16-bit draws, rng.h).  Uniform / bit / ternary: fixed-position
 // draws, eight per keystream block (the reference's keying, one stream - i.e. at least
 // one block - per residue, made the generator the whole cost of the call).  Integers are
 // drawn once and written as residues into every limb; the result is transformed to EVAL.
@@ -147,14 +147,14 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];  // exactly 32 KB: five workgroups per CU
+    __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
     const size_t total = polys << logN;  // polys < 2^32 (checked by the launcher)
     const size_t N = static_cast<size_t>(1) << logN;
     WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
     KarneyFsm f;
-    f.st = KS_DONE;
+    karney_reset(f);
     bool have = false;
     size_t idx = 0;
     for (uint32_t step = 0;; ++step) {
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                if (f.st != KS_IDLE) rng_fill<10>(rng);
+                rng_fill_wave(rng, f.st != KS_IDLE);
             }
             karney_heavy(f, rng);
         }

@@ -26,12 +26,18 @@ static constexpr uint64_t kTagP1 = 0x7065727475726231ull;
 static constexpr int kGaussMaxDigits = 64;
 
 // ---- G-lattice sampler ------------------------------------------------------------------------
+// The stream of element (polynomial p, tower t, coefficient i): sub-key (seed, kTagGadget, 0) - one per call -,
+// stream0 = (i + 1) 2^8 + (t + 1) (at most 64 towers), stream1 = p + 1.
+__host__ __device__ __forceinline__ uint64_t gadget_stream0(uint32_t i, uint32_t t) {
+    return ((static_cast<uint64_t>(i) + 1) << 8) | (static_cast<uint64_t>(t) + 1);
+}
+
 template <typename W, int MAXD>
 __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out, const W *__restrict__ src,
                                      const LimbConst *__restrict__ limbs, size_t src_polys, uint32_t src_cols,
                                      uint32_t L, uint32_t N, uint32_t dpt, uint32_t base_bits, double c, size_t k,
                                      GpuRngSeed seed) {
-    __shared__ uint64_t ring[128 * RNG_RING_WORDS];
+    __shared__ uint32_t ring[128 * RNG_RING_SLOTS];
     const size_t idx = item_index();
     const size_t total = src_polys * L * N;
     if (idx >= total) return;
@@ -65,11 +71,10 @@ __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out,
         }
     }
     ChaChaRng rng;
-    rng_init(rng, ring, seed, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1,
-             static_cast<uint64_t>(i) + 1, kTagGadget);
+    rng_init(rng, ring, seed, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 0, kTagGadget);
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) {
-        if ((d & 3) == 0) rng_fill(rng);  // 4 normals = 8 words per checkpoint
+        if ((d & 3) == 0) rng_fill_lane(rng);  // 4 normals = 32 draws per checkpoint
         zf[d] = d < (int)dpt ? sigma * rng_standard_normal(rng) : 0.0;
     }
 
@@ -144,13 +149,6 @@ __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out,
 }
 
 // ---- G-lattice sampler, persistent-lane form (dpt <= 4; rng.h explains the scheme) -------------
-// The stream of element (p, t, i) is keyed by stream2 = i+1, so its HChaCha20 sub-key depends on
-// the coefficient index only: one table of N sub-keys per call instead of one derivation per element.
-__global__ void gadget_keys_kernel(ChaChaKey *__restrict__ keys, uint32_t N, GpuRngSeed seed) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) keys[i] = chacha_subkey(seed, static_cast<uint64_t>(i) + 1, kTagGadget);
-}
-
 // per-tower constants of the sampler: c_last = c_{dpt-1} of the tower's modulus digits, the width
 // sigma / c_last of the first Karney integer and its divisor
 struct GqTower {
@@ -176,15 +174,14 @@ __global__ void gq_tower_kernel(GqTower *__restrict__ towers, const LimbConst *_
     towers[t] = g;
 }
 
-// Pass 1, fully convergent: the dpt normals every element draws first (words 0..2*dpt-1 of its
-// stream) and the centres a_d they imply.  a_out is [dpt][total]; the 8 - 2*dpt words of keystream
-// block 0 the normals did not use are handed to pass 2 in left_out ([8 - 2*dpt][total]).
+// Pass 1, fully convergent: the dpt normals every element draws first (draws 0..8*dpt-1 = 64-bit words 0..2*dpt-1 of
+// keystream block 0) and the centres a_d they imply.  a_out is [dpt][total]; the 8 - 2*dpt 64-bit words of block 0 the
+// normals did not use are handed to pass 2 in left_out ([8 - 2*dpt][total]).
 template <typename W, int MAXD>
 __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict__ a_out, uint64_t *__restrict__ left_out,
                                        const W *__restrict__ src, const LimbConst *__restrict__ limbs,
-                                       const ChaChaKey *__restrict__ keys, size_t total, uint32_t L, uint32_t logN,
+                                       ChaChaKey key, size_t total, uint32_t L, uint32_t logN,
                                        uint32_t dpt, uint32_t base_bits, double c) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];
     const size_t idx = item_index();
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
@@ -198,13 +195,15 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     const double sigma = c / (base_f + 1.0);
     const double kf = static_cast<double>(dpt);
 
-    ChaChaRng rng;
-    rng_init_keyed(rng, ring, keys[i], static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1);
-    rng_fill(rng);  // 8 words >= 2 * MAXD
+    uint64_t w[8];
+    chacha_block_words(key, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 0, w);
     double zf[MAXD];
 #pragma unroll
-    for (int d = 0; d < MAXD; ++d) zf[d] = d < (int)dpt ? sigma * rng_standard_normal(rng) : 0.0;
-    for (uint32_t w = 0; w < 8 - 2 * dpt; ++w) left_out[static_cast<size_t>(w) * total + idx] = rng_next_u64(rng);
+    for (int d = 0; d < MAXD; ++d)
+        zf[d] = d < (int)dpt ? sigma * (sqrt(-2.0 * det_log(u64_to_open01(w[2 * d]))) * det_cos2pi(u64_to_open01(w[2 * d + 1]))) : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j >= 2 * (int)dpt) left_out[static_cast<size_t>(j - 2 * (int)dpt) * total + idx] = w[j];
     double prev_a = 0.0;
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) {
@@ -227,17 +226,23 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     }
 }
 
+// refill cadence of pass 2: an element starts with the 16 - 8 * dpt .. 24 draws block 0 left over, enough for the
+// first checkpoint or two, so refills can be held to every second checkpoint
+#ifndef GSAMP_FILL_EVERY
+#define GSAMP_FILL_EVERY 2
+#endif
+#define GSAMP_FILL_SCHEDULE(step) (GSAMP_FILL_EVERY == 1 || (((step) >> 3) % GSAMP_FILL_EVERY) == 0)
 // Pass 2: the dpt Karney integers of every element.  Wave w owns elements [w*64*per_lane,
 // +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
 template <typename W, int MAXD>
 __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ src,
-                                        const LimbConst *__restrict__ limbs, const ChaChaKey *__restrict__ keys,
+                                        const LimbConst *__restrict__ limbs, ChaChaKey key,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
                                         uint32_t L, uint32_t logN, uint32_t dpt, uint32_t base_bits, double c,
                                         KarneyDivisor div_sigma, uint32_t per_lane) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];  // exactly 32 KB: five workgroups per CU
+    __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
     const uint64_t base = 1ull << base_bits;
     const double base_f = static_cast<double>(base);
     const double sigma = c / (base_f + 1.0);
@@ -246,9 +251,9 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
     WaveChunk chunk = wave_chunk(total, per_lane);
 
     ChaChaRng rng;
-    rng_init_keyed(rng, ring, ChaChaKey{}, 0, 0);
+    rng_init_keyed(rng, ring, key, 0, 0);
     KarneyFsm f;
-    f.st = KS_DONE;
+    karney_reset(f);
     bool fin = true, have = false;
     uint32_t ph = 0;
     size_t idx = 0;
@@ -320,14 +325,16 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                         qt = limbs[t].q;
                         value = static_cast<uint64_t>(src[idx]);
                         if (value >= qt) value %= qt;
-                        const ChaChaKey key = keys[i];
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) rng.state[4 + w] = key.w[w];
-                        // block 0 went to pass 1: take its unused words, continue at block 1
-                        rng_reopen(rng, static_cast<uint64_t>(t) + 1, static_cast<uint64_t>(p) + 1, 1);
-                        for (uint32_t w = 0; w < nleft; ++w)
-                            rng.ring[((rng.tail + w) & (RNG_RING_WORDS - 1)) * rng.ring_stride] = left_in[static_cast<size_t>(w) * total + idx];
-                        rng.tail += nleft;
+                        // block 0 went to pass 1: its unused words are draws 8*dpt..31 of the stream, continue at block 1
+                        rng_reopen(rng, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 1);
+                        const uint32_t slot0 = (rng.tail >> 1) & (RNG_RING_SLOTS - 1);
+                        for (uint32_t w = 0; w < nleft; ++w) {
+                            const uint64_t lw = left_in[static_cast<size_t>(w) * total + idx];
+                            rng.ring[(slot0 + 4 * dpt + 2 * w) * rng.ring_stride] = static_cast<uint32_t>(lw);
+                            rng.ring[(slot0 + 4 * dpt + 2 * w + 1) * rng.ring_stride] = static_cast<uint32_t>(lw >> 32);
+                        }
+                        rng.head = rng.tail + 8 * dpt;
+                        rng.tail += RNG_BLOCK_DRAWS;
                         double a_last = 0.0;
 #pragma unroll
                         for (int d = 0; d < MAXD; ++d) {
@@ -345,7 +352,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                if (f.st != KS_IDLE) rng_fill<10>(rng);
+                rng_fill_wave(rng, f.st != KS_IDLE, GSAMP_FILL_SCHEDULE(step));
             }
             karney_heavy(f, rng);
         }
@@ -378,40 +385,35 @@ __global__ void __launch_bounds__(256) gauss_samp_expand_kernel(W *__restrict__ 
 template <typename W, int MAXD>
 static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t total, uint32_t src_cols, uint32_t L,
                                    uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
-    const uint32_t N = static_cast<uint32_t>(ctx->N);
     if ((total >> ctx->logN) >> 32 || k >> 32) return set_error("gpu_matrix_gauss_samp_gq_arb_base: matrix too large");
-    // [N] sub-keys | [L] towers | [8][total] words between passes 1 and 2 | [total][dpt] digits
-    void *keys = nullptr, *towers = nullptr, *a_buf = nullptr, *stage = nullptr;
-    if (ctx_alloc(ctx, static_cast<size_t>(N) * sizeof(ChaChaKey), &keys) ||
-        ctx_alloc(ctx, static_cast<size_t>(L) * sizeof(GqTower), &towers) ||
+    // [L] towers | [8][total] words between passes 1 and 2 | [total][dpt] digits
+    void *towers = nullptr, *a_buf = nullptr, *stage = nullptr;
+    if (ctx_alloc(ctx, static_cast<size_t>(L) * sizeof(GqTower), &towers) ||
         ctx_alloc(ctx, total * 8 * sizeof(uint64_t), &a_buf) || ctx_alloc(ctx, total * dpt * sizeof(int64_t), &stage)) {
-        ctx_free(ctx, keys);
         ctx_free(ctx, towers);
         ctx_free(ctx, a_buf);
         return 1;
     }
     double *a_words = static_cast<double *>(a_buf);
     uint64_t *left_words = static_cast<uint64_t *>(a_buf) + total * dpt;
-    MXX_LAUNCH(gadget_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream,
-                       static_cast<ChaChaKey *>(keys), N, seed);
+    const ChaChaKey key = chacha_subkey(seed, 0, kTagGadget);
     MXX_LAUNCH(gq_tower_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<GqTower *>(towers), ctx->d_limbs,
                        L, dpt, base_bits, c);
     MXX_LAUNCH((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
-                       ctx->stream, a_words, left_words, src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys), total, L,
+                       ctx->stream, a_words, left_words, src, ctx->d_limbs, key, total, L,
                        ctx->logN, dpt, base_bits, c);
     const uint32_t per_lane =
         sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device, ctx->env.sampler_per_lane);
     const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
-                       static_cast<int64_t *>(stage), src, ctx->d_limbs, static_cast<const ChaChaKey *>(keys),
+                       static_cast<int64_t *>(stage), src, ctx->d_limbs, key,
                        static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
                        base_bits, c, karney_divisor(sigma), per_lane);
     MXX_LAUNCH(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
                        ctx->stream, out, static_cast<const int64_t *>(stage), ctx->d_limbs, total, src_cols, L, ctx->logN,
                        dpt, static_cast<uint32_t>(k));
     const hipError_t err = hipGetLastError();
-    ctx_free(ctx, keys);
     ctx_free(ctx, towers);
     ctx_free(ctx, a_buf);
     ctx_free(ctx, stage);
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(128) p1_sample_kernel(W *__restrict__ out, con
                                  const double *__restrict__ update_base, uint32_t m, uint32_t cols, uint32_t L,
                                  uint32_t N, uint64_t q0, double c_scale, GpuRngSeed seed,
                                  double *__restrict__ mean_ws) {
-    __shared__ uint64_t ring[128 * RNG_RING_WORDS];
+    __shared__ uint32_t ring[128 * RNG_RING_SLOTS];
     const size_t idx = item_index();
     if (idx >= static_cast<size_t>(cols) * N) return;
     const uint32_t col = static_cast<uint32_t>(idx / N);
@@ -599,12 +601,12 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
                                        const KarneyDivisor *__restrict__ div_base, uint32_t m, uint32_t cols, uint32_t L,
                                        uint32_t logN, uint64_t q0, double c_scale, ChaChaKey key, size_t total,
                                        uint32_t per_lane) {
-    __shared__ uint64_t ring[256 * RNG_RING_WORDS];  // exactly 32 KB: five workgroups per CU
+    __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
     WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
     KarneyFsm f;
-    f.st = KS_DONE;
+    karney_reset(f);
     bool fin = true, have = false;
     uint32_t t = 0, col = 0, i = 0;
     double mean[MAXM], mu = 0.0;
@@ -659,7 +661,7 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                if (f.st != KS_IDLE) rng_fill<10>(rng);
+                rng_fill_wave(rng, f.st != KS_IDLE);
             }
             karney_heavy(f, rng);
         }

@@ -144,6 +144,8 @@ def _bind_sampling(L):
     ]
     L.orc_karney.restype = None
     L.orc_karney.argtypes = [_u64p, C.c_uint64, C.c_double, C.c_double, _i64p, C.c_size_t]
+    L.orc_karney_ties.restype = C.c_ulonglong
+    L.orc_karney_ties.argtypes = []
     L.orc_gauss_samp_gq.restype = None
     L.orc_gauss_samp_gq.argtypes = [
         _u64p, _u64p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p, C.c_uint32, C.c_double, _u64p,
@@ -347,6 +349,11 @@ def karney_samples(seed, s0, mean, stddev, count) -> np.ndarray:
     out = np.zeros(count, dtype=np.int64)
     lib().orc_karney(_p(_seed_words(seed)), s0, float(mean), float(stddev), out.ctypes.data_as(_i64p), count)
     return out
+
+
+def karney_ties() -> int:
+    """Comparisons of Karney's sampler that tied on the 16-bit draw and needed the low bits, since the library was loaded."""
+    return int(lib().orc_karney_ties())
 
 
 DIST = {"uniform": 0, "gauss": 1, "bit": 2, "ternary": 3}

@@ -37,7 +37,7 @@ double orc_det_cos2pi(double u) { return det_cos2pi(u); }
 typedef struct {
     uint32_t state[16];
     uint32_t block[16];
-    uint32_t pos;
+    uint32_t pos; /* next 16-bit draw of the current block, 0..32 */
 } rng_t;
 
 static inline uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
@@ -79,17 +79,27 @@ static void rng_init(rng_t *r, const uint64_t seed[4], uint64_t s0, uint64_t s1,
     r->state[12] = 0; r->state[13] = (uint32_t)s0;
     r->state[14] = (uint32_t)s1;
     r->state[15] = ((uint32_t)(s0 >> 32) & 0xffffu) | ((uint32_t)(s1 >> 32) << 16);
-    r->pos = 8;
+    r->pos = 32;
 }
 
-static uint64_t rng_u64(rng_t *r) {
-    if (r->pos >= 8) {
+/* The keystream is consumed as little-endian 16-bit draws, 32 per ChaCha20 block (mxx_amd/csrc/rng.h: Karney's
+ * uniform deviates are only ever compared, so 16 bits decide all but one comparison in 65536; a 64-bit word is four
+ * consecutive draws, i.e. the same bytes as before whenever it starts on a multiple of four draws). */
+static uint32_t rng_draw16(rng_t *r) {
+    if (r->pos >= 32) {
         orc_chacha20_block(r->state, r->block);
         ++r->state[12];
         r->pos = 0;
     }
-    uint64_t v = (uint64_t)r->block[2 * r->pos] | ((uint64_t)r->block[2 * r->pos + 1] << 32);
+    const uint32_t w = r->block[r->pos >> 1];
+    const uint32_t v = (r->pos & 1u) ? (w >> 16) : (w & 0xffffu);
     ++r->pos;
+    return v;
+}
+
+static uint64_t rng_u64(rng_t *r) {
+    uint64_t v = 0;
+    for (int i = 0; i < 4; ++i) v |= (uint64_t)rng_draw16(r) << (16 * i);
     return v;
 }
 
@@ -114,15 +124,57 @@ static double std_normal(rng_t *r) {
 }
 
 
-/* Karney, "Sampling exactly from the normal distribution" (arXiv:1303.6257), algorithm D */
+/* Karney, "Sampling exactly from the normal distribution" (arXiv:1303.6257), algorithm D, with the reference's
+ * iteration caps (cuda/src/matrix/MatrixSampling.cu:30-147).  A uniform deviate is m 2^-53 with the integer
+ * m = max(hi 2^37 + lo, 1): hi is one 16-bit draw, lo (37 bits: three more draws, d1 2^21 + d2 2^5 + (d3 >> 11)) is drawn
+ * only when a comparison ties on hi - the threshold's lo first if it is itself a deviate whose lo is still undrawn, then
+ * the deviate's.  Every comparison is therefore the one the reference makes on 53-bit deviates ("u < t" on doubles ==
+ * "m < ceil(t 2^53)" on integers); only the keystream spent on it differs. */
+typedef struct {
+    uint32_t hi;  /* up to 65536 for the constant 1.0 */
+    uint64_t lo;
+    int known;
+} lazy_t;
+
+static unsigned long long g_karney_ties; /* test hook: comparisons that needed the low bits */
+unsigned long long orc_karney_ties(void) { return g_karney_ties; }
+
+static lazy_t lz_const(double t) { /* t in [0, 1] */
+    const uint64_t ticks = (uint64_t)ceil(t * 9007199254740992.0);
+    lazy_t v = {(uint32_t)(ticks >> 37), ticks & ((1ull << 37) - 1), 1};
+    return v;
+}
+static lazy_t lz_draw(rng_t *r) {
+    lazy_t v = {rng_draw16(r), 0, 0};
+    return v;
+}
+static void lz_materialise(rng_t *r, lazy_t *v) {
+    if (v->known) return;
+    const uint64_t d1 = rng_draw16(r), d2 = rng_draw16(r), d3 = rng_draw16(r);
+    uint64_t lo = (d1 << 21) | (d2 << 5) | (d3 >> 11);
+    if (v->hi == 0 && lo == 0) lo = 1; /* the deviate is never 0 */
+    v->lo = lo;
+    v->known = 1;
+}
+static int lz_less(rng_t *r, lazy_t *u, lazy_t *t) {
+    if (u->hi < t->hi) return 1;
+    if (u->hi > t->hi) return 0;
+#pragma omp atomic
+    ++g_karney_ties;
+    lz_materialise(r, t);
+    lz_materialise(r, u);
+    return u->lo < t->lo;
+}
+
 static int k_h(rng_t *r) {
-    double a = u01(r);
-    if (!(a < 0.5)) return 1;
+    lazy_t half = lz_const(0.5);
+    lazy_t a = lz_draw(r);
+    if (!lz_less(r, &a, &half)) return 1;
     for (;;) {
-        double b = u01(r);
-        if (!(b < a)) return 0;
-        a = u01(r);
-        if (!(a < b)) return 1;
+        lazy_t b = lz_draw(r);
+        if (!lz_less(r, &b, &a)) return 0;
+        a = lz_draw(r);
+        if (!lz_less(r, &a, &b)) return 1;
     }
 }
 static int32_t k_g(rng_t *r) {
@@ -135,14 +187,14 @@ static int k_p(rng_t *r, int32_t n) {
     return n < 0;
 }
 static int k_b(rng_t *r, int32_t k, double x) {
-    double y = x;
+    lazy_t y = lz_const(x);
+    lazy_t thr = lz_const((2.0 * (double)k + x) / (double)(2 * k + 2));
     int32_t n = 0;
-    const double m = (double)(2 * k + 2);
     for (;; ++n) {
-        double z = u01(r);
-        if (!(z < y)) break;
-        double rr = u01(r);
-        if (!(rr < (2.0 * (double)k + x) / m)) break;
+        lazy_t z = lz_draw(r);
+        if (!lz_less(r, &z, &y)) break;
+        lazy_t rr = lz_draw(r);
+        if (!lz_less(r, &rr, &thr)) break;
         y = z;
         if (n > 4096) break;
     }
@@ -155,7 +207,7 @@ static int64_t karney(rng_t *r, double mean, double stddev) {
     for (int iter = 0; iter < (1 << 16); ++iter) {
         int32_t k = k_g(r);
         if (!k_p(r, k * (k - 1))) continue;
-        int64_t s = (rng_u64(r) & 1ull) ? 1 : -1;
+        int64_t s = (rng_draw16(r) & 1u) ? 1 : -1;
         double di0 = stddev * (double)k + (double)s * mean;
         int64_t i0 = (int64_t)ceil(di0);
         double x0 = ((double)i0 - di0) / stddev;
@@ -274,7 +326,8 @@ void orc_gauss_samp_gq(uint64_t *out, const uint64_t *src, size_t rows, size_t c
                 uint64_t vv = src[((size_t)p * L + t) * n + i] % qt;
                 for (uint32_t d = 0; d < dpt; ++d) { vd[d] = (int64_t)(vv % base); vv /= base; }
                 rng_t r;
-                rng_init(&r, seed, (uint64_t)t + 1, (uint64_t)p + 1, (uint64_t)i + 1, 0x6761646765746731ull);
+                /* one sub-key per call; stream0 = (coefficient + 1) 2^8 + (tower + 1), stream1 = polynomial + 1 */
+                rng_init(&r, seed, (((uint64_t)i + 1) << 8) | ((uint64_t)t + 1), (uint64_t)p + 1, 0, 0x6761646765746731ull);
                 for (uint32_t d = 0; d < dpt; ++d) zf[d] = sigma * std_normal(&r);
                 for (uint32_t d = 0; d + 1 < dpt; ++d) pp[d] = l_[d] * zf[d] + h_[d + 1] * zf[d + 1];
                 pp[dpt - 1] = h_[dpt - 1] * zf[dpt - 1];

@@ -81,6 +81,19 @@ def test_sample_distribution_bit_exact(gpu, oracle, n, depth, bits, base, dist, 
     assert not (gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, code, sigma, seed(gpu, 1)) == m)
 
 
+def test_gauss_million_samples_cover_the_tie_path(gpu, oracle):
+    """2^20 Gaussian integers, bit for bit: with 16-bit draws about one comparison in 65536 ties and takes the
+    low-bits path (KS_TIE on the device, lz_less in the restatement) - a few hundred times here, counted by the oracle."""
+    p = make_params(gpu, oracle, 16384, 2, 24, 12)
+    s = seed(gpu, 33)
+    before = oracle.karney_ties()
+    want = oracle.sample_distribution(8, 8, p.moduli(), 16384, "gauss", 4.578, s)
+    ties = oracle.karney_ties() - before
+    assert ties >= 100, ties
+    m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 8, 8, oracle.DIST["gauss"], 4.578, s)
+    assert np.array_equal(m.to_coeff_rns(), want)
+
+
 @pytest.mark.parametrize("per_lane", ["1", "3", "16"])
 @pytest.mark.parametrize("n,rows,cols,sigma", [(128, 2, 3, 4.578), (1024, 1, 5, 8191.5)])
 def test_gauss_persistent_lanes_bit_exact(gpu, oracle, hip_env, per_lane, n, rows, cols, sigma):

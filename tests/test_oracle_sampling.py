@@ -171,3 +171,16 @@ def test_p1_sampler_statistics():
     resid = z - mu
     assert abs(resid.mean()) < 5 * s / np.sqrt(resid.size) * 2
     assert abs(resid[1].std() / s - 1) < 0.1
+
+
+def test_karney_lazy_deviates_tie_path_is_exercised_and_unbiased():
+    """Round 3 keying: a uniform deviate is one 16-bit draw, its 37 low bits are drawn only when a comparison ties
+    (one in 65536).  Over 400 k integers the tie path runs hundreds of times; the moments stay those of the discrete
+    Gaussian (a wrong tie rule would bias every 4000th sample, far below what moments see - the point of this test is
+    that the path RUNS here on the CPU; the GPU tests compare it bit for bit against this restatement)."""
+    before = O.karney_ties()
+    x = O.karney_samples(SEED, 11, 0.37, 4.578, 400000).astype(np.float64)
+    ties = O.karney_ties() - before
+    assert 30 <= ties <= 400, ties   # ~17 comparisons per integer / 65536
+    assert abs(x.mean() - 0.37) < 0.03
+    assert abs(x.std() - 4.578) < 0.03
