@@ -189,10 +189,14 @@ __device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
 // Wave-convergent checkpoint of the persistent-lane kernels: EVERY lane of the wave calls it (idle lanes with
 // live = false); call once per 8 steps.  A live lane with room for a block (at most 32 draws left) "wants" one; it
 // is "urgent" from 20 draws down (8 steps + two service points take at most 19) and "starving" below 6.
-// Policy (MXX_FILL_POLICY, compile time; profiles/r03_notes.md has the A/B):
-//   a pass happens when the checkpoint is `scheduled` and some lane is urgent, or when 16 lanes are starving;
-//   in a pass every wanting lane computes its own block (960 instructions for up to 64 blocks).
-// MXX_FILL_POLICY == 1 adds the cooperative form for passes with fewer than 40 wanting lanes: the first 16 get a quad
+// A pass happens when the checkpoint is `scheduled` and some lane is urgent, or when 16 lanes are starving; in a pass
+// every wanting lane computes its own block (960 instructions for up to 64 blocks).  A lane that runs dry between
+// passes waits (it only consumes draws it holds), so holding passes to every second or third checkpoint trades a few
+// idle lane-steps for whole passes: the kernels choose `scheduled` (G-sampler every third checkpoint - an element
+// starts with block 0's leftover draws -, p1 every second, the Gaussian matrix every one: its elements are one
+// integer long and start empty).
+// make CXXFLAGS+=-DMXX_FILL_POLICY=1 builds the cooperative form instead (measured, not the default:
+// profiles/r03_notes.md): for passes with fewer than 40 wanting lanes the first 16 get a quad
 // each; lane c of the quad holds column c of the requester's state (its counter / nonce words fetched with
 // ds_bpermute, key and constants are uniform), column rounds in place, diagonal rounds with rows b, c, d rotated by
 // 1, 2, 3 lanes through DPP, and writes its four output words into the requester's ring (same bytes either way;
@@ -315,7 +319,8 @@ __device__ __forceinline__ double u64_to_open01(uint64_t w) {
 
 // needs 2 words.  Box-Muller with detmath.h's log / cos(2 pi u): fixed IEEE operation sequences,
 // so the CPU restatement reproduces every normal bit for bit (sqrt is exactly rounded on both sides)
-__device__ __forceinline__ double rng_standard_normal(ChaChaRng &rng) {
+template <typename RNG>
+__device__ __forceinline__ double rng_standard_normal(RNG &rng) {
     double u1 = u64_to_open01(rng_next_u64(rng));
     double u2 = u64_to_open01(rng_next_u64(rng));
     return sqrt(-2.0 * det_log(u1)) * det_cos2pi(u2);
@@ -482,7 +487,8 @@ __device__ __forceinline__ void karney_advance(KarneyFsm &f, bool lt, uint32_t h
 }
 
 // one cheap step
-__device__ __forceinline__ void karney_light(KarneyFsm &f, ChaChaRng &rng) {
+template <typename RNG>
+__device__ __forceinline__ void karney_light(KarneyFsm &f, RNG &rng) {
     if (f.st > KS_B1 || rng_avail(rng) == 0) return;
     const uint32_t h = rng_next16(rng);
     if (h == f.T_hi) {  // one comparison in 65536: the low bits decide, at the next service point
@@ -495,14 +501,16 @@ __device__ __forceinline__ void karney_light(KarneyFsm &f, ChaChaRng &rng) {
 }
 
 // the 37 low bits of a deviate: three draws
-__device__ __forceinline__ uint64_t karney_draw_lo(ChaChaRng &rng, uint32_t hi) {
+template <typename RNG>
+__device__ __forceinline__ uint64_t karney_draw_lo(RNG &rng, uint32_t hi) {
     const uint64_t d1 = rng_next16(rng), d2 = rng_next16(rng), d3 = rng_next16(rng);
     const uint64_t lo = (d1 << 21) | (d2 << 5) | (d3 >> 11);
     return (hi == 0 && lo == 0) ? 1 : lo;  // a deviate is never 0
 }
 
 // the expensive transitions; call at wave-convergent service points
-__device__ __forceinline__ void karney_heavy(KarneyFsm &f, ChaChaRng &rng) {
+template <typename RNG>
+__device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
     if (f.st == KS_SIGN && rng_avail(rng) >= 5) {
         const uint32_t w1 = rng_next16(rng);
         const uint64_t w2 = rng_next_u64(rng);

@@ -144,6 +144,11 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 // (sub-key shared by all).  Lanes finish at different times, so a lane's store is a lone 8 bytes:
 // it goes to a compact int64 staging array ([poly][N]) that a coalesced pass expands into the L
 // residues per coefficient (storing the residues from here cost a 32-byte HBM write per limb).
+// refills at every checkpoint: a coefficient is one integer (~21 draws) and starts with an empty ring, so some lane of
+// the wave is out of draws at every checkpoint whatever the cadence (every 2nd: 2.40 against 2.41 ms on M3A)
+#ifndef GAUSS_FILL_EVERY
+#define GAUSS_FILL_EVERY 1
+#endif
 __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane) {
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE);
+                rng_fill_wave(rng, f.st != KS_IDLE, ((step >> 3) % GAUSS_FILL_EVERY) == 0);
             }
             karney_heavy(f, rng);
         }

@@ -226,10 +226,11 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     }
 }
 
-// refill cadence of pass 2: an element starts with the 16 - 8 * dpt .. 24 draws block 0 left over, enough for the
-// first checkpoint or two, so refills can be held to every second checkpoint
+// refill cadence of pass 2: an element starts with the 32 - 8 * dpt draws block 0 left over, enough for the first
+// checkpoint or two, so refills are held to every third checkpoint (same-box A/B on M3A, lanes kernel: every
+// checkpoint 3.33 ms, every 2nd 2.78, every 3rd 2.63, every 4th 2.74; profiles/r03_notes.md)
 #ifndef GSAMP_FILL_EVERY
-#define GSAMP_FILL_EVERY 2
+#define GSAMP_FILL_EVERY 3
 #endif
 #define GSAMP_FILL_SCHEDULE(step) (GSAMP_FILL_EVERY == 1 || (((step) >> 3) % GSAMP_FILL_EVERY) == 0)
 // Pass 2: the dpt Karney integers of every element.  Wave w owns elements [w*64*per_lane,
@@ -593,6 +594,10 @@ __global__ void p1_divisor_kernel(KarneyDivisor *__restrict__ div, const double 
     if (idx < count) div[idx] = karney_divisor(sqrt_var[idx]);
 }
 
+// refills every second checkpoint (p1 lanes kernel on M3A: 0.47 -> 0.445 ms; every third 0.447)
+#ifndef P1_FILL_EVERY
+#define P1_FILL_EVERY 2
+#endif
 // persistent-lane form for m <= 4 (rng.h): element = (column, coefficient), m dependent Karney
 // integers each (rows m-1 .. 0); integers go to the int64 staging array [row][col][N]
 template <typename W, int MAXM>
@@ -661,7 +666,7 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE);
+                rng_fill_wave(rng, f.st != KS_IDLE, ((step >> 3) % P1_FILL_EVERY) == 0);
             }
             karney_heavy(f, rng);
         }
