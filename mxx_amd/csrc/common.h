@@ -45,6 +45,7 @@ struct EnvSwitches {
     bool gsamp_simple = false;    // MXX_HIP_GSAMP=simple
     bool p1_simple = false;       // MXX_HIP_P1=simple
     int sampler_per_lane = 0;     // MXX_HIP_SAMPLER_PER_LANE (0 = sized for one resident round)
+    int sampler_fill_every = 0;   // MXX_HIP_SAMPLER_FILL_EVERY = 1..8: keystream refill cadence of the Gaussian lane kernels in checkpoints (0 = per kernel default)
     bool ntt64_int = false;       // MXX_HIP_NTT64=int: 64-bit words keep the integer butterflies (A/B, tests)
     void load();
 };

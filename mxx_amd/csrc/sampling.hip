@@ -144,14 +144,11 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 // (sub-key shared by all).  Lanes finish at different times, so a lane's store is a lone 8 bytes:
 // it goes to a compact int64 staging array ([poly][N]) that a coalesced pass expands into the L
 // residues per coefficient (storing the residues from here cost a 32-byte HBM write per limb).
-// refills at every checkpoint: a coefficient is one integer (~21 draws) and starts with an empty ring, so some lane of
+// fill_every = 1, refills at every checkpoint: a coefficient is one integer (~21 draws) and starts with an empty ring, so some lane of
 // the wave is out of draws at every checkpoint whatever the cadence (every 2nd: 2.40 against 2.41 ms on M3A)
-#ifndef GAUSS_FILL_EVERY
-#define GAUSS_FILL_EVERY 1
-#endif
 __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
-                                    double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane) {
+                                    double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every) {
     __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
     const size_t total = polys << logN;  // polys < 2^32 (checked by the launcher)
     const size_t N = static_cast<size_t>(1) << logN;
@@ -181,7 +178,7 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE, ((step >> 3) % GAUSS_FILL_EVERY) == 0);
+                rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
             }
             karney_heavy(f, rng);
         }
@@ -219,7 +216,8 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
         MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
-                           static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane);
+                           static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,
+                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 1));
         const hipError_t err = hipGetLastError();
         const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
         ctx_free(ctx, stage);

@@ -226,13 +226,11 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     }
 }
 
-// refill cadence of pass 2: an element starts with the 32 - 8 * dpt draws block 0 left over, enough for the first
-// checkpoint or two, so refills are held to every third checkpoint (same-box A/B on M3A, lanes kernel: every
-// checkpoint 3.33 ms, every 2nd 2.78, every 3rd 2.63, every 4th 2.74; profiles/r03_notes.md)
-#ifndef GSAMP_FILL_EVERY
-#define GSAMP_FILL_EVERY 3
-#endif
-#define GSAMP_FILL_SCHEDULE(step) (GSAMP_FILL_EVERY == 1 || (((step) >> 3) % GSAMP_FILL_EVERY) == 0)
+// refill cadence of pass 2 (fill_every, in checkpoints): an element starts with the 32 - 8 * dpt draws block 0 has left
+// over.  With 16 of them (dpt <= 2) that is enough for the first checkpoint or two, so refills are held to every
+// third checkpoint (same-box A/B on M3A, lanes kernel: every checkpoint 3.33 ms, every 2nd 2.78, every 3rd 2.63,
+// every 4th 2.74; profiles/r03_notes.md); with fewer or none left (dpt = 3, 4) the longer elements still make every
+// third the best cadence (tools/time_gsamp.py: 0.572 / 0.537 / 0.527 / 0.533 ms at dpt = 3, 0.686 / 0.666 / 0.640 / 0.657 at 4).
 // Pass 2: the dpt Karney integers of every element.  Wave w owns elements [w*64*per_lane,
 // +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
@@ -242,7 +240,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
                                         uint32_t L, uint32_t logN, uint32_t dpt, uint32_t base_bits, double c,
-                                        KarneyDivisor div_sigma, uint32_t per_lane) {
+                                        KarneyDivisor div_sigma, uint32_t per_lane, uint32_t fill_every) {
     __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
     const uint64_t base = 1ull << base_bits;
     const double base_f = static_cast<double>(base);
@@ -353,7 +351,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE, GSAMP_FILL_SCHEDULE(step));
+                rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
             }
             karney_heavy(f, rng);
         }
@@ -410,7 +408,8 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
     MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
                        static_cast<int64_t *>(stage), src, ctx->d_limbs, key,
                        static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
-                       base_bits, c, karney_divisor(sigma), per_lane);
+                       base_bits, c, karney_divisor(sigma), per_lane,
+                       static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3));
     MXX_LAUNCH(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
                        ctx->stream, out, static_cast<const int64_t *>(stage), ctx->d_limbs, total, src_cols, L, ctx->logN,
                        dpt, static_cast<uint32_t>(k));
@@ -594,18 +593,15 @@ __global__ void p1_divisor_kernel(KarneyDivisor *__restrict__ div, const double 
     if (idx < count) div[idx] = karney_divisor(sqrt_var[idx]);
 }
 
-// refills every second checkpoint (p1 lanes kernel on M3A: 0.47 -> 0.445 ms; every third 0.447)
-#ifndef P1_FILL_EVERY
-#define P1_FILL_EVERY 2
-#endif
 // persistent-lane form for m <= 4 (rng.h): element = (column, coefficient), m dependent Karney
-// integers each (rows m-1 .. 0); integers go to the int64 staging array [row][col][N]
+// integers each (rows m-1 .. 0); integers go to the int64 staging array [row][col][N].  Keystream refills every
+// second checkpoint (fill_every; M3A: 0.47 -> 0.445 ms, every third 0.447)
 template <typename W, int MAXM>
 __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ tp2,
                                        const double *__restrict__ sqrt_var_base, const double *__restrict__ update_base,
                                        const KarneyDivisor *__restrict__ div_base, uint32_t m, uint32_t cols, uint32_t L,
                                        uint32_t logN, uint64_t q0, double c_scale, ChaChaKey key, size_t total,
-                                       uint32_t per_lane) {
+                                       uint32_t per_lane, uint32_t fill_every) {
     __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
     WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
@@ -666,7 +662,7 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
                     }
                 }
                 if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE, ((step >> 3) % P1_FILL_EVERY) == 0);
+                rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
             }
             karney_heavy(f, rng);
         }
@@ -807,7 +803,8 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
         MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(256), 0, ctx->stream,          \
                            static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,    \
                            cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m, \
-                           (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane);          \
+                           (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,           \
+                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2)); \
     } while (0)
         if (ctx->wide) {
             if (m <= 2) LAUNCH_P1L(uint64_t, 2);
