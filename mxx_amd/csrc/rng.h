@@ -195,7 +195,7 @@ __device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
 // idle lane-steps for whole passes: the kernels choose `scheduled` (G-sampler every third checkpoint - an element
 // starts with block 0's leftover draws -, p1 every second, the Gaussian matrix every one: its elements are one
 // integer long and start empty).
-// make CXXFLAGS+=-DMXX_FILL_POLICY=1 builds the cooperative form instead (measured, not the default:
+// `make FILL_POLICY=1` builds the cooperative form instead (measured, not the default:
 // profiles/r03_notes.md): for passes with fewer than 40 wanting lanes the first 16 get a quad
 // each; lane c of the quad holds column c of the requester's state (its counter / nonce words fetched with
 // ds_bpermute, key and constants are uniform), column rounds in place, diagonal rounds with rows b, c, d rotated by
