@@ -639,6 +639,42 @@ extern "C" int gpupoly_matrix_add_rows(GpuMatrix *out, size_t dst_row, const Gpu
     ABI_GUARD_END
 }
 
+// Extension: out[dst_row .. dst_row + coeff.rows) = NTT(coeff) + addend.  `coeff` holds coefficients and is left
+// untouched, `addend` is EVAL of the same shape; the transform, the sum and the placement into a row block of a taller
+// matrix are one pass where a fused kernel exists (2^14, 32-bit words: ntt14::fwd_add_kernel), otherwise a copy, a
+// transform in place and an addition.  The preimage's bottom block p2 + z is the caller (mxx_amd/trapdoor.py;
+// src/sampler/trapdoor/gpu.rs:340-369 transforms z, then adds): z's EVAL form is never materialised.
+extern "C" int gpupoly_matrix_ntt_add_rows(GpuMatrix *out, size_t dst_row, const GpuMatrix *coeff, const GpuMatrix *addend) {
+    ABI_GUARD_BEGIN
+    if (!out || !coeff || !addend) return set_error("gpupoly_matrix_ntt_add_rows: null matrix");
+    if (matrix_check_same_shape(coeff, addend, "gpupoly_matrix_ntt_add_rows")) return 1;
+    if (out->ctx != coeff->ctx || out->level != coeff->level) return set_error("gpupoly_matrix_ntt_add_rows: context/level mismatch");
+    if (out->cols != coeff->cols || dst_row > out->rows || coeff->rows > out->rows - dst_row)
+        return set_error("gpupoly_matrix_ntt_add_rows: row block out of range");
+    if (coeff->format != GPU_POLY_FORMAT_COEFF || addend->format != GPU_POLY_FORMAT_EVAL)
+        return set_error("gpupoly_matrix_ntt_add_rows: expects a COEFF matrix and an EVAL addend");
+    if (out == coeff || out == addend) return set_error("gpupoly_matrix_ntt_add_rows: output must not alias an input");
+    GpuContext *ctx = out->ctx;
+    out->format = GPU_POLY_FORMAT_EVAL;  // the whole destination, as add_rows / copy_block do
+    const size_t polys = matrix_polys(coeff);
+    if (polys == 0) return 0;
+    if (ctx_activate(ctx)) return 1;
+    const size_t L = matrix_limbs(out);
+    const size_t poly_bytes = L * static_cast<size_t>(ctx->N) * ctx->word_bytes;
+    GpuMatrix view = matrix_view(out, dst_row * out->cols, coeff->rows, coeff->cols, poly_bytes);
+    view.format = GPU_POLY_FORMAT_EVAL;
+    if (!ctx->wide) {
+        const int rc = launch_ntt_add_u32(ctx, static_cast<uint32_t *>(view.data), static_cast<const uint32_t *>(coeff->data),
+                                          static_cast<const uint32_t *>(addend->data), polys * L, static_cast<uint32_t>(L));
+        if (rc >= 0) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(view.data, coeff->data, view.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = launch_ntt(ctx, view.data, polys * L, static_cast<int>(L), false);
+    if (rc) return rc;
+    return launch_elementwise<OP_ADD, false>(&view, &view, addend);  // in place: every word is read, then written
+    ABI_GUARD_END
+}
+
 extern "C" int gpu_matrix_add(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs) {
     ABI_GUARD_BEGIN
     if (matrix_check_same_shape(out, lhs, "gpu_matrix_add") || matrix_check_same_shape(lhs, rhs, "gpu_matrix_add"))

@@ -106,6 +106,7 @@ struct GpuMatrix {
     int format = GPU_POLY_FORMAT_EVAL;
     void *data = nullptr;  // words [rows*cols][level+1][N]
     size_t bytes = 0;
+    bool borrowed = false;  // a row-block view of another matrix (gpupoly_matrix_row_view): data is not freed with it
 };
 
 struct GpuEventSet {
@@ -227,6 +228,7 @@ int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t
 int launch_ntt_digits_u64(GpuContext *ctx, uint64_t *out, const uint64_t *coeff, size_t out_vectors, uint32_t L,
                           uint32_t src_cols, uint32_t towers, uint32_t dpt, uint32_t base_bits, size_t k);
 // out <- INTT(in o w), w one resident EVAL-form ring element [L][N]; -1: no fused kernel for this context
+int launch_ntt_add_u32(GpuContext *ctx, uint32_t *out, const uint32_t *src, const uint32_t *add, size_t vectors, uint32_t L);
 int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, const uint32_t *w, size_t vectors, uint32_t L);
 int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);
 int launch_matmul_dma_u32(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);  // -1: shape not supported

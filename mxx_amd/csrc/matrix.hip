@@ -221,9 +221,27 @@ extern "C" int gpu_matrix_create(GpuContext *ctx, int level, size_t rows, size_t
     ABI_GUARD_END
 }
 
+// Extension: a matrix object over rows [row, row + rows) of `m` - a contiguous block of the row-major layout - that
+// shares m's storage: operands of a product or a sum without the slice's copy.  The view carries its own format tag
+// (initialised from m's); it must be destroyed before m, and m must not be resized meanwhile (nothing here resizes).
+extern "C" int gpupoly_matrix_row_view(GpuMatrix *m, size_t row, size_t rows, GpuMatrix **out_view) {
+    ABI_GUARD_BEGIN
+    if (!m || !out_view) return set_error("gpupoly_matrix_row_view: null argument");
+    if (row > m->rows || rows > m->rows - row) return set_error("gpupoly_matrix_row_view: row block out of range");
+    const size_t poly_bytes = matrix_limbs(m) * static_cast<size_t>(m->ctx->N) * m->ctx->word_bytes;
+    GpuMatrix *v = new GpuMatrix(*m);
+    v->rows = rows;
+    v->data = rows && m->cols ? static_cast<char *>(m->data) + row * m->cols * poly_bytes : nullptr;
+    v->bytes = rows * m->cols * poly_bytes;
+    v->borrowed = true;
+    *out_view = v;
+    return 0;
+    ABI_GUARD_END
+}
+
 extern "C" void gpu_matrix_destroy(GpuMatrix *mat) {
     if (!mat) return;
-    if (mat->data) {
+    if (mat->data && !mat->borrowed) {
         (void)hipSetDevice(mat->ctx->device);
         ctx_free(mat->ctx, mat->data);  // stream-ordered: in-flight kernels finish first
     }

@@ -49,9 +49,10 @@ __device__ __forceinline__ void wave_sync() {
 // output: a k-times larger matrix that nothing reads back from cache, source vectors re-read by L * dpt workgroups: decompose 18.5 -> 17.9 ms, same-box A/B); wrong for
 // the plain transform, whose output the next kernel often finds in the Infinity Cache (M1: the fused inverse behind a
 // forward transform with such stores ran 158 -> 185 us).
-template <typename W, bool TIGHT, bool NTS, typename Load>
+// ADD: the vector `addv` (canonical residues, evaluation order) is added to the result on its way out
+template <typename W, bool TIGHT, bool NTS, typename Load, bool ADD = false>
 __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> *__restrict__ tw_all,
-                                         const LimbConst &lc, uint32_t limb) {
+                                         const LimbConst &lc, uint32_t limb, const W *__restrict__ addv = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *xs = reinterpret_cast<W *>(smem);  // [2][8][BLK_PAD]
     constexpr int VN = 16 / sizeof(W);
@@ -113,6 +114,11 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
                 wx t;
 #pragma unroll
                 for (int e = 0; e < VN; ++e) t[e] = v[m + e];
+                if constexpr (ADD) {
+                    const wx a = __builtin_nontemporal_load(reinterpret_cast<const wx *>(addv + B * BLK + 8 * lane + m));
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) t[e] = csub<W>(t[e] + a[e], q);
+                }
                 if constexpr (NTS) __builtin_nontemporal_store(t, reinterpret_cast<wx *>(dst + m));
                 else *reinterpret_cast<wx *>(dst + m) = t;
             }
@@ -140,6 +146,19 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     const LimbConst lc = limbs[limb];
     W *g = data + vec * N;
     fwd_body<W, TIGHT, NT>(g, LoadVector<W, NT>{g}, tw_all, lc, limb);
+}
+
+// out = NTT(src) + add, out of place: the preimage's x = [.. ; p2 + z] takes the G-sampler's coefficient digits, the
+// perturbation and the output block in ONE pass (gpupoly_matrix_ntt_add_rows) instead of a transform in place
+// followed by an addition: 1.97 GB of traffic instead of 3.28 at M3A
+template <typename W, bool TIGHT = false>
+__global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
+    fwd_add_kernel(W *__restrict__ out, const W *__restrict__ src, const W *__restrict__ add,
+                   const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs, uint32_t L) {
+    const uint32_t limb = blockIdx.x;
+    const size_t vec = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * L + limb;
+    const LimbConst lc = limbs[limb];
+    fwd_body<W, TIGHT, true, LoadVector<W, true>, true>(out + vec * N, LoadVector<W, true>{src + vec * N}, tw_all, lc, limb, add + vec * N);
 }
 
 // Gadget decomposition fused into the transform's load (decompose.hip): output vector

@@ -16,6 +16,22 @@ int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, cons
     return launch_mul_intt(ctx, out, in, w, vectors, L);
 }
 
+// out = NTT(src) + add in one pass (ntt14.h, fwd_add_kernel); -1: no fused kernel for this context / path override,
+// the caller then copies, transforms in place and adds
+int launch_ntt_add_u32(GpuContext *ctx, uint32_t *out, const uint32_t *src, const uint32_t *add, size_t vectors, uint32_t L) {
+    const EnvSwitches &env = ctx->env;
+    if (ctx->logN != 14 || !(ctx->lazy_ok || ctx->tight_ok) || env.ntt14 == 1 || env.ntt_path > 1) return -1;
+    dim3 grid, block(ntt14::T);
+    if (vectors > 0x7fffffffull || !ntt14_grid(vectors, L, grid)) return -1;
+    const size_t lds = ntt14::lds_bytes(sizeof(W));
+    const TwPair<W> *tw = static_cast<const TwPair<W> *>(ctx->d_tw2_fwd);
+    if (ctx->lazy_ok) MXX_LAUNCH((ntt14::fwd_add_kernel<W, false>), grid, block, lds, ctx->stream, out, src, add, tw, ctx->d_limbs, L);
+    else MXX_LAUNCH((ntt14::fwd_add_kernel<W, true>), grid, block, lds, ctx->stream, out, src, add, tw, ctx->d_limbs, L);
+    HIP_TRY(hipGetLastError());
+    ctx->last_kernel = "ntt14::fwd_add_kernel";
+    return 0;
+}
+
 // decompose + forward NTT in one pass (ntt14.h, fwd_digits_kernel); -1: not available for this
 // context / path override, the caller then runs the digit kernel and the transform separately
 int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff, size_t out_vectors, uint32_t L,

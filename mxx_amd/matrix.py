@@ -59,7 +59,7 @@ class GpuP1CovarianceCache:
 
 
 class GpuDCRTPolyMatrix:
-    __slots__ = ("params", "nrow", "ncol", "level", "is_ntt", "raw", "_finalizer", "__weakref__")
+    __slots__ = ("params", "nrow", "ncol", "level", "is_ntt", "raw", "_finalizer", "_parent", "__weakref__")
 
     # ------------------------------------------------------------------ construction
     def __init__(self, params: GpuDCRTPolyParams, nrow: int, ncol: int, level: int, is_ntt: bool):
@@ -76,6 +76,7 @@ class GpuDCRTPolyMatrix:
         self.level = level
         self.is_ntt = is_ntt
         self.raw = raw
+        self._parent = None  # set on row views: the matrix whose storage this one shares
         self._finalizer = weakref.finalize(self, _ffi.lib().gpu_matrix_destroy, raw)
 
     @classmethod
@@ -436,6 +437,27 @@ class GpuDCRTPolyMatrix:
             rhs = rhs.ensure_eval() if lhs.is_ntt else rhs.ensure_coeff()
         check_status(_ffi.lib().gpupoly_matrix_add_rows(self.raw, dst_row, lhs.raw, rhs.raw), "gpupoly_matrix_add_rows")
         self.is_ntt = lhs.is_ntt
+
+    def row_view(self, row_start, row_end) -> "GpuDCRTPolyMatrix":
+        """Rows [row_start, row_end) as a matrix that shares this one's storage (gpupoly_matrix_row_view): an operand
+        without the slice's copy.  The view keeps its parent alive; writes through either are seen by both."""
+        assert 0 <= row_start <= row_end <= self.nrow
+        raw = C.c_void_p()
+        check_status(_ffi.lib().gpupoly_matrix_row_view(self.raw, row_start, row_end - row_start, C.byref(raw)), "gpupoly_matrix_row_view")
+        v = object.__new__(GpuDCRTPolyMatrix)
+        v.params, v.nrow, v.ncol, v.level, v.is_ntt, v.raw = self.params, row_end - row_start, self.ncol, self.level, self.is_ntt, raw
+        v._parent = self
+        v._finalizer = weakref.finalize(v, _ffi.lib().gpu_matrix_destroy, raw)
+        return v
+
+    def ntt_add_rows_from(self, dst_row, coeff, addend) -> None:
+        """self[dst_row : dst_row + coeff.nrow] = NTT(coeff) + addend (gpupoly_matrix_ntt_add_rows): `coeff` holds
+        coefficients and stays as it is, `addend` is EVAL; one pass where the fused kernel exists."""
+        assert coeff.size() == addend.size() and coeff.ncol == self.ncol and dst_row + coeff.nrow <= self.nrow
+        assert not coeff.is_ntt, "ntt_add_rows_from takes a coefficient-domain matrix"
+        addend = addend.ensure_eval()
+        check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(self.raw, dst_row, coeff.raw, addend.raw), "gpupoly_matrix_ntt_add_rows")
+        self.is_ntt = True
 
     def slice(self, row_start, row_end, col_start, col_end) -> "GpuDCRTPolyMatrix":
         nrow, ncol = row_end - row_start, col_end - col_start
@@ -904,9 +926,12 @@ class GpuDCRTPolyMatrix:
         check_status(st, "gpupoly_matrix_sample_decomposed")
         return out
 
-    def gauss_samp_gq_arb_base(self, c: float, dgg_stddev: float, seed: GpuRngSeed) -> "GpuDCRTPolyMatrix":
-        """Consumes self (gpu_dcrt_poly.rs:509-528)."""
-        out = GpuDCRTPolyMatrix.new_empty(self.params, self.nrow * self.params.modulus_digits(), self.ncol)
+    def gauss_samp_gq_arb_base(self, c: float, dgg_stddev: float, seed: GpuRngSeed, coeff_out: bool = False) -> "GpuDCRTPolyMatrix":
+        """Consumes self (gpu_dcrt_poly.rs:509-528).  coeff_out: leave the digits as coefficients (the entry point
+        finishes in whatever format the output matrix is tagged with) for a caller that transforms them itself
+        (`ntt_add_rows_from`)."""
+        out = GpuDCRTPolyMatrix(self.params, self.nrow * self.params.modulus_digits(), self.ncol, self.params.crt_depth() - 1,
+                                not coeff_out)
         self.intt_all_in_place()
         st = _ffi.lib().gpu_matrix_gauss_samp_gq_arb_base(self.raw, self.params.base_bits(), c, dgg_stddev, seed, out.raw)
         check_status(st, "gpu_matrix_gauss_samp_gq_arb_base")

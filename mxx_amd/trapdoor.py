@@ -112,6 +112,16 @@ class GpuDCRTTrapdoor:
     __hash__ = None
 
 
+TRAFFIC_BOUND_BYTES = 32 << 20  # tests set it to 0 to run the large-operand assembly at small sizes
+
+
+def _traffic_bound(params, polys: int) -> bool:
+    """A matrix of `polys` polynomials is large enough (32 MiB) for the passes over it, not the launches, to be the cost:
+    the preimage then trades a few small launches for whole passes over its largest operands."""
+    word = 4 if max(params.moduli()) < (1 << 31) else 8
+    return polys * params.crt_depth() * params.ring_dimension() * word >= TRAFFIC_BOUND_BYTES
+
+
 class GpuDCRTPolyTrapdoorSampler:
     def __init__(self, params, sigma: float):
         self.sigma = float(sigma)
@@ -136,16 +146,26 @@ class GpuDCRTPolyTrapdoorSampler:
         a1 = g - (a_bar * td.r + td.e)
         return td, a0.concat_columns([a1])
 
-    def _sample_pert(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol):
-        """`sample_pert_square_mat_gpu_native_parts` (gpu.rs:423-474)."""
+    def _sample_pert(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol, right=None):
+        """`sample_pert_square_mat_gpu_native_parts` (gpu.rs:423-474).  With `right` (the public matrix's columns over
+        p2) the product right * p2 the caller needs next rides in the same pass over p2 as [R;E] p2: one product with the
+        stacked left factor.  Returns p1, p2, [R;E] p2 (EVAL, kept for the final assembly) and right * p2 (or None)."""
         u = GpuDCRTPolyUniformSampler()
         d, dk = td.r.row_size(), td.r.col_size()
         padded = -(-total_ncol // d) * d
         p2 = u.sample_uniform(params, dk, padded, DistType.GaussDist(sigma_large))
-        tp2 = td.re * p2
+        rp2 = None
+        if right is not None and _traffic_bound(params, dk * padded):
+            t = td.re.concat_rows([right]) * p2
+            tp2 = t.slice(0, td.re.row_size(), 0, padded)
+            rp2 = t.slice(td.re.row_size(), t.row_size(), 0, padded)
+        else:
+            tp2 = td.re * p2
+        # the p1 sampler takes its argument to the coefficient domain in place
+        tp2_eval = tp2.clone() if _traffic_bound(params, dk * padded) else None
         cache = td.p1_covariance_cache(c, s, dgg_stddev)
         p1 = GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2, random_gpu_rng_seed())
-        return p1, p2
+        return p1, p2, tp2_eval, rp2
 
     def preimage(self, params, td: GpuDCRTTrapdoor, public_matrix, target) -> GpuDCRTPolyMatrix:
         """x with public_matrix * x == target (gpu.rs:228-369)."""
@@ -155,22 +175,32 @@ class GpuDCRTPolyTrapdoorSampler:
         n, k = params.ring_dimension(), params.modulus_digits()
         s = preimage_smoothing_parameter(self.base, self.sigma, d, n, k)
         dgg_large_std = math.sqrt(s * s - self.c * self.c)
-        p1, p2 = self._sample_pert(params, td, s, self.c, self.sigma, dgg_large_std, target_cols)
-        p1_rows, p2_rows = p1.row_size(), p2.row_size()
+        p1_rows, p2_rows = td.re.row_size(), td.re.col_size()
         assert public_matrix.col_size() == p1_rows + p2_rows, "public matrix columns must match perturbation rows"
         left = public_matrix.slice(0, d, 0, p1_rows)
         right = public_matrix.slice(0, d, p1_rows, p1_rows + p2_rows)
-        p_hat_image = (left * p1) + (right * p2)
+        p1, p2, tp2, rp2 = self._sample_pert(params, td, s, self.c, self.sigma, dgg_large_std, target_cols, right)
+        assert (p1.row_size(), p2.row_size()) == (p1_rows, p2_rows)
+        p_hat_image = (left * p1) + (rp2 if rp2 is not None else right * p2)
         if p_hat_image.col_size() != target_cols:
             p_hat_image = p_hat_image.slice_columns(0, target_cols)
         perturbed = target - p_hat_image
-        z_hat = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed())
-        # x = [p1 + [R;E] z ; p2 + z].  The reference forms R z and E z separately (gpu.rs:340-362); one product
-        # with the stacked factor reads the large z once - same residues.
-        re_z = td.re * z_hat
         out = GpuDCRTPolyMatrix(params, p1_rows + p2_rows, target_cols, p1.level, p1.is_ntt)
-        if p1.col_size() == target_cols and p1_rows == re_z.row_size() and p2_rows == z_hat.row_size():
-            # the sums are written straight into out's row blocks: 3 passes over the operands instead of 5
+        if p1.col_size() == target_cols and tp2 is not None:
+            # x = [p1 + [R;E] z ; p2 + z] (gpu.rs:340-362 transforms z, forms R z and E z, adds twice).  Here the
+            # G-sampler's digits stay coefficients and ONE pass writes the bottom block NTT(z) + p2 into its place;
+            # the top block follows from it, [R;E] z = [R;E] (p2 + z) - [R;E] p2, with the product read straight
+            # from the output's rows and [R;E] p2 kept from the perturbation step - same residues, and z's
+            # evaluation form (the largest matrix of the call) is never written or re-read.
+            z = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed(), coeff_out=True)
+            out.ntt_add_rows_from(p1_rows, z, p2)
+            re_x = td.re * out.row_view(p1_rows, p1_rows + p2_rows)
+            out.add_rows_from(0, p1 - tp2, re_x)
+            return out
+        z_hat = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed())
+        re_z = td.re * z_hat
+        if p1.col_size() == target_cols:
+            # small operands (launch-bound): the sums written straight into out's row blocks, 3 passes instead of 5
             out.add_rows_from(0, p1, re_z)
             out.add_rows_from(p1_rows, p2, z_hat)
             return out

@@ -186,12 +186,19 @@ def test_gauss_samp_gq_bit_exact(gpu, oracle, hip_env, n, depth, bits, base, for
     assert np.array_equal(z_gpu, oracle.gauss_samp_gq(M, moduli, base, c, s))
 
 
-@pytest.mark.parametrize("n,depth,bits,base,d,cols", [(256, 2, 24, 12, 1, 3), (64, 2, 51, 17, 2, 2), (128, 2, 16, 4, 2, 3)])
-def test_whole_preimage_replays_on_the_cpu(gpu, oracle, n, depth, bits, base, d, cols):
+@pytest.mark.parametrize("assembly", ["small", "large"])
+@pytest.mark.parametrize("n,depth,bits,base,d,cols", [(256, 2, 24, 12, 1, 3), (64, 2, 51, 17, 2, 2), (128, 2, 16, 4, 2, 3),
+                                                      (16384, 2, 24, 12, 1, 2)])
+def test_whole_preimage_replays_on_the_cpu(gpu, oracle, monkeypatch, n, depth, bits, base, d, cols, assembly):
     """Trapdoor generation and a preimage call with the OS seeds replaced by fixed ones (the test-only
     hook mxx_amd.sampler.seed_source): R, E, A and the preimage x are bit-identical to the CPU chain
-    oracle.trapdoor_gen / oracle.preimage (restating src/sampler/trapdoor/gpu.rs:202-369)."""
+    oracle.trapdoor_gen / oracle.preimage (restating src/sampler/trapdoor/gpu.rs:202-369).  Both assemblies of the
+    result: the small-operand one (products and sums as the reference forms them) and the large-operand one (stacked
+    left factor over p2, NTT(z) + p2 in one pass, the top block from the output's own rows; 2^14 takes the fused kernel)."""
+    import mxx_amd.trapdoor as trapdoor_mod
     from mxx_amd.sampler import seed_source
+
+    monkeypatch.setattr(trapdoor_mod, "TRAFFIC_BOUND_BYTES", 0 if assembly == "large" else 1 << 62)
 
     p = make_params(gpu, oracle, n, depth, bits, base)
     moduli = p.moduli()

@@ -414,6 +414,57 @@ def test_add_rows_extension(gpu, oracle):
         _ffi.check_status(_ffi.lib().gpupoly_matrix_add_rows(out.raw, 4, ga.raw, gb.raw), "gpupoly_matrix_add_rows")
 
 
+@pytest.mark.parametrize("n,depth,bits", [(16384, 3, 24), (16384, 2, 28), (256, 2, 24), (16384, 2, 51), (64, 2, 51)])
+def test_ntt_add_rows_extension(gpu, oracle, n, depth, bits):
+    """gpupoly_matrix_ntt_add_rows: out[r0 : r0 + rows] = NTT(coeff) + addend in one call - the fused 2^14 kernel
+    (lazy and tight forms), and the copy / transform / add fall-back at other rings and with 64-bit words; the source
+    stays as it was, the other rows of the destination too."""
+    from mxx_amd import _ffi
+
+    p = make_params(gpu, oracle, n, depth, bits, 12)
+    moduli = p.moduli()
+    base = rand_matrix(oracle, 510, 4, 3, moduli, n)
+    z, a = rand_matrix(oracle, 511, 2, 3, moduli, n), rand_matrix(oracle, 512, 2, 3, moduli, n)
+    z[0, 0, :, :4] = 0
+    z[1, 2] = (np.asarray(moduli, dtype=np.uint64) - 1)[:, None]  # extreme inputs
+    a[1, 2] = (np.asarray(moduli, dtype=np.uint64) - 1)[:, None]
+    out = gpu.GpuDCRTPolyMatrix.from_rns(p, base, True)
+    gz, ga = gpu.GpuDCRTPolyMatrix.from_rns(p, z, False), gpu.GpuDCRTPolyMatrix.from_rns(p, a, True)
+    out.ntt_add_rows_from(1, gz, ga)
+    want = base.copy()
+    want[1:3] = oracle.pointwise("add", oracle.matrix_ntt(z, moduli), a, moduli)
+    assert out.is_ntt and np.array_equal(out.to_rns(), want)
+    assert not gz.is_ntt and np.array_equal(gz.to_coeff_rns(), z)
+    with pytest.raises(gpu.GpuPolyError):  # an EVAL source is refused, and so is a block past the last row
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(out.raw, 1, ga.raw, ga.raw), "gpupoly_matrix_ntt_add_rows")
+    with pytest.raises(gpu.GpuPolyError):
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(out.raw, 3, gz.raw, ga.raw), "gpupoly_matrix_ntt_add_rows")
+
+
+def test_row_view_extension(gpu, oracle):
+    """gpupoly_matrix_row_view: a row block as a matrix that shares its parent's storage - a product operand without
+    the slice's copy; writes through the parent are seen by the view and the other way round; the parent outlives it."""
+    import gc
+
+    n = 256
+    p = make_params(gpu, oracle, n, 2, 24, 12)
+    moduli = p.moduli()
+    m = rand_matrix(oracle, 520, 5, 3, moduli, n)
+    left = rand_matrix(oracle, 521, 2, 3, moduli, n)
+    gm = gpu.GpuDCRTPolyMatrix.from_rns(p, m, True)
+    v = gm.row_view(1, 4)
+    assert (v.row_size(), v.col_size()) == (3, 3) and np.array_equal(v.to_rns(), m[1:4])
+    prod = gpu.GpuDCRTPolyMatrix.from_rns(p, left, True) * v
+    assert np.array_equal(prod.to_rns(), oracle.matmul(left, m[1:4], moduli))
+    gm.add_rows_from(2, gpu.GpuDCRTPolyMatrix.from_rns(p, m[0:1], True), gpu.GpuDCRTPolyMatrix.from_rns(p, m[4:5], True))
+    assert np.array_equal(v.to_rns()[1], oracle.pointwise("add", m[0:1], m[4:5], moduli)[0])
+    del gm  # the view keeps the storage alive
+    gc.collect()
+    assert np.array_equal(v.to_rns()[0], m[1])
+    empty = gpu.GpuDCRTPolyMatrix.from_rns(p, m, True).row_view(5, 5)
+    assert empty.row_size() == 0
+
+
 @pytest.mark.parametrize("n,depth,bits", [(64, 3, 24), (256, 3, 51), (8, 2, 31)])
 def test_mul_batch_extension(gpu, oracle, n, depth, bits):
     """gpupoly_matrix_mul_batch: a level's independent products in one call - mixed shapes, more than one launch's worth
