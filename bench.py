@@ -953,7 +953,7 @@ def main():
         del m1
         if d.world == 1:
             line["kernels"]["large_batch"] = large_batch_kernels(mx, device)
-        if d.rank == 0 and not args.no_cpu_baseline:
+        if d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:  # an N = 1 leg: the other ranks would wait for it
             line["cpu_baseline"] = cpu_baseline("m2a", args.cpu_seconds)
             line["preimage"]["cpu_baseline"] = cpu_baseline("m3a", args.cpu_seconds)
             line["kernels"]["cpu_baseline"] = cpu_baseline("m1", args.cpu_seconds / 2)
@@ -965,7 +965,7 @@ def main():
             if d.world == 1:
                 del wl
                 line["kernels"]["large_batch"] = large_batch_kernels(mx, device)
-        if d.rank == 0 and not args.no_cpu_baseline:
+        if d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:  # an N = 1 leg: the other ranks would wait for it
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
     if d.rank == 0:
         line.setdefault("cpu_baseline", None)
