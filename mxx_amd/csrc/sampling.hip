@@ -159,30 +159,35 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
     karney_reset(f);
     bool have = false;
     size_t idx = 0;
-    for (uint32_t step = 0;; ++step) {
-        if ((step & 3) == 0) {
-            if ((step & 7) == 0) {
-                const bool take = f.st == KS_DONE;  // write the finished coefficient, open the next one's stream
-                if (take && have) stage[idx] = f.result;
-                const uint32_t e = wave_take(chunk, take);
-                if (take) {
-                    have = e < chunk.len;
-                    if (have) {
-                        idx = chunk.base + e;
-                        const uint32_t p = static_cast<uint32_t>(idx >> logN);
-                        const uint32_t row = p / local_ncol, lcol = p - row * local_ncol;
-                        rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx & (N - 1)) + 1);
-                        karney_begin(f, 0.0, sigma, div);
-                    } else {
-                        f.st = KS_IDLE;
-                    }
+    // a superstep = 8 steps: checkpoint (finished coefficient out, next one in, keystream), then twice [service point,
+    // four cheap steps].  Written out instead of `if ((step & 3) == 0)` inside a one-step loop: the compiler then keeps
+    // the state machine in place instead of copying ~30 registers around the branch on every step.
+    for (uint32_t step = 0;; step += 8) {
+        {
+            const bool take = f.st == KS_DONE;  // write the finished coefficient, open the next one's stream
+            if (take && have) stage[idx] = f.result;
+            const uint32_t e = wave_take(chunk, take);
+            if (take) {
+                have = e < chunk.len;
+                if (have) {
+                    idx = chunk.base + e;
+                    const uint32_t p = static_cast<uint32_t>(idx >> logN);
+                    const uint32_t row = p / local_ncol, lcol = p - row * local_ncol;
+                    rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx & (N - 1)) + 1);
+                    karney_begin(f, 0.0, sigma, div);
+                } else {
+                    f.st = KS_IDLE;
                 }
-                if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
             }
-            karney_heavy(f, rng);
+            if (__all(f.st == KS_IDLE)) break;
+            rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
         }
-        karney_light(f, rng);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            karney_heavy(f, rng);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) karney_light(f, rng);
+        }
     }
 }
 

@@ -263,99 +263,109 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) { a[d] = 0.0; z[d] = 0; }
 
-    for (uint32_t step = 0;; ++step) {
-        if ((step & 3) == 0) {
-            if (f.st == KS_DONE && !fin) {  // an integer of the current element is ready
-                if (ph == 0) {
-                    z_last = f.result;
-                    double prev_c = 0.0;
+    // a superstep = 8 steps: checkpoint, then twice [finished integer handed on, service point, four cheap steps].
+    // Written out instead of `if ((step & 3) == 0)` inside a one-step loop: the compiler then keeps the state machine
+    // in place instead of copying ~30 registers around the branch on every step (sample_gauss_kernel: 2.42 -> 2.26 ms).
+    auto integer_ready = [&]() {
+        if (f.st == KS_DONE && !fin) {  // an integer of the current element is ready
+            if (ph == 0) {
+                z_last = f.result;
+                double prev_c = 0.0;
 #pragma unroll
-                    for (int d = 0; d < MAXD; ++d) {
-                        if (d < (int)dpt) {
-                            const double cd = (prev_c + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
-                            prev_c = cd;
-                            a[d] += static_cast<double>(z_last) * cd;
-                        }
+                for (int d = 0; d < MAXD; ++d) {
+                    if (d < (int)dpt) {
+                        const double cd = (prev_c + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
+                        prev_c = cd;
+                        a[d] += static_cast<double>(z_last) * cd;
                     }
-                } else {
-#pragma unroll
-                    for (int d = 0; d < MAXD; ++d)
-                        if (d == (int)ph - 1) z[d] = f.result;
                 }
-                ++ph;
-                if (ph == dpt) {
-                    fin = true;
-                } else {
-                    double an = 0.0;
+            } else {
 #pragma unroll
-                    for (int d = 0; d < MAXD; ++d)
-                        if (d == (int)ph - 1) an = a[d];
-                    karney_begin(f, -an, sigma, div_sigma);
-                }
+                for (int d = 0; d < MAXD; ++d)
+                    if (d == (int)ph - 1) z[d] = f.result;
             }
-            if ((step & 7) == 0) {
-                const bool take = f.st == KS_DONE && fin;  // element complete: write its digits, take the next one
-                if (take && have) {
-                    int64_t z_prev = 0;
+            ++ph;
+            if (ph == dpt) {
+                fin = true;
+            } else {
+                double an = 0.0;
 #pragma unroll
-                    for (int d = 0; d < MAXD; ++d) {
-                        if (d < (int)dpt) {
-                            const int64_t md = static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1));
-                            const int64_t vd = static_cast<int64_t>((value >> (base_bits * d)) & (base - 1));
-                            const int64_t zd = d < last ? z[d] : z_last;
-                            int64_t digit;
-                            if (dpt == 1) digit = static_cast<int64_t>(base) * zd + md * zd + vd;
-                            else if (d == 0) digit = static_cast<int64_t>(base) * zd + md * z_last + vd;
-                            else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
-                            else digit = md * z_last - z_prev + vd;
-                            z_prev = zd;
-                            stage[idx * dpt + d] = digit;
-                        }
-                    }
-                }
-                const uint32_t e = wave_take(chunk, take);
-                if (take) {
-                    have = e < chunk.len;
-                    if (have) {
-                        idx = chunk.base + e;
-                        const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
-                        const uint32_t pt = static_cast<uint32_t>(idx >> logN);
-                        const uint32_t p = pt / L, t = pt - p * L;
-                        qt = limbs[t].q;
-                        value = static_cast<uint64_t>(src[idx]);
-                        if (value >= qt) value %= qt;
-                        // block 0 went to pass 1: its unused words are draws 8*dpt..31 of the stream, continue at block 1
-                        rng_reopen(rng, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 1);
-                        const uint32_t slot0 = (rng.tail >> 1) & (RNG_RING_SLOTS - 1);
-                        for (uint32_t w = 0; w < nleft; ++w) {
-                            const uint64_t lw = left_in[static_cast<size_t>(w) * total + idx];
-                            rng.ring[(slot0 + 4 * dpt + 2 * w) * rng.ring_stride] = static_cast<uint32_t>(lw);
-                            rng.ring[(slot0 + 4 * dpt + 2 * w + 1) * rng.ring_stride] = static_cast<uint32_t>(lw >> 32);
-                        }
-                        rng.head = rng.tail + 8 * dpt;
-                        rng.tail += RNG_BLOCK_DRAWS;
-                        double a_last = 0.0;
-#pragma unroll
-                        for (int d = 0; d < MAXD; ++d) {
-                            if (d < (int)dpt) {
-                                a[d] = a_in[static_cast<size_t>(d) * total + idx];
-                                a_last = a[d];
-                            }
-                        }
-                        ph = 0;
-                        fin = false;
-                        const GqTower tw = towers[t];
-                        karney_begin(f, -a_last / tw.c_last, tw.sd, tw.div);
-                    } else {
-                        f.st = KS_IDLE;
-                    }
-                }
-                if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
+                for (int d = 0; d < MAXD; ++d)
+                    if (d == (int)ph - 1) an = a[d];
+                karney_begin(f, -an, sigma, div_sigma);
             }
-            karney_heavy(f, rng);
         }
-        karney_light(f, rng);
+    };
+    auto element_done = [&]() {  // element complete: write its digits, take the next one
+        const bool take = f.st == KS_DONE && fin;  // element complete: write its digits, take the next one
+        if (take && have) {
+            int64_t z_prev = 0;
+#pragma unroll
+            for (int d = 0; d < MAXD; ++d) {
+                if (d < (int)dpt) {
+                    const int64_t md = static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1));
+                    const int64_t vd = static_cast<int64_t>((value >> (base_bits * d)) & (base - 1));
+                    const int64_t zd = d < last ? z[d] : z_last;
+                    int64_t digit;
+                    if (dpt == 1) digit = static_cast<int64_t>(base) * zd + md * zd + vd;
+                    else if (d == 0) digit = static_cast<int64_t>(base) * zd + md * z_last + vd;
+                    else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
+                    else digit = md * z_last - z_prev + vd;
+                    z_prev = zd;
+                    stage[idx * dpt + d] = digit;
+                }
+            }
+        }
+        const uint32_t e = wave_take(chunk, take);
+        if (take) {
+            have = e < chunk.len;
+            if (have) {
+                idx = chunk.base + e;
+                const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
+                const uint32_t pt = static_cast<uint32_t>(idx >> logN);
+                const uint32_t p = pt / L, t = pt - p * L;
+                qt = limbs[t].q;
+                value = static_cast<uint64_t>(src[idx]);
+                if (value >= qt) value %= qt;
+                // block 0 went to pass 1: its unused words are draws 8*dpt..31 of the stream, continue at block 1
+                rng_reopen(rng, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 1);
+                const uint32_t slot0 = (rng.tail >> 1) & (RNG_RING_SLOTS - 1);
+                for (uint32_t w = 0; w < nleft; ++w) {
+                    const uint64_t lw = left_in[static_cast<size_t>(w) * total + idx];
+                    rng.ring[(slot0 + 4 * dpt + 2 * w) * rng.ring_stride] = static_cast<uint32_t>(lw);
+                    rng.ring[(slot0 + 4 * dpt + 2 * w + 1) * rng.ring_stride] = static_cast<uint32_t>(lw >> 32);
+                }
+                rng.head = rng.tail + 8 * dpt;
+                rng.tail += RNG_BLOCK_DRAWS;
+                double a_last = 0.0;
+#pragma unroll
+                for (int d = 0; d < MAXD; ++d) {
+                    if (d < (int)dpt) {
+                        a[d] = a_in[static_cast<size_t>(d) * total + idx];
+                        a_last = a[d];
+                    }
+                }
+                ph = 0;
+                fin = false;
+                const GqTower tw = towers[t];
+                karney_begin(f, -a_last / tw.c_last, tw.sd, tw.div);
+            } else {
+                f.st = KS_IDLE;
+            }
+        }
+    };
+    for (uint32_t step = 0;; step += 8) {
+        integer_ready();
+        element_done();
+        if (__all(f.st == KS_IDLE)) break;
+        rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
+        karney_heavy(f, rng);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
+        integer_ready();
+        karney_heavy(f, rng);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
     }
 }
 
@@ -614,59 +624,67 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
 #pragma unroll
     for (int r = 0; r < MAXM; ++r) mean[r] = 0.0;
 
-    for (uint32_t step = 0;; ++step) {
-        if ((step & 3) == 0) {
-            if (f.st == KS_DONE && !fin) {  // the integer of row t is ready
-                const int64_t z = f.result;
-                stage[((static_cast<size_t>(t) * cols + col) << logN) + i] = z;
-                const double delta = static_cast<double>(z) - mu;
-                const double *upd = update_base + (static_cast<size_t>(i) * m + t) * m;
+    // supersteps of 8 as in gauss_samp_lanes_kernel
+    auto integer_ready = [&]() {
+        if (f.st == KS_DONE && !fin) {  // the integer of row t is ready
+            const int64_t z = f.result;
+            stage[((static_cast<size_t>(t) * cols + col) << logN) + i] = z;
+            const double delta = static_cast<double>(z) - mu;
+            const double *upd = update_base + (static_cast<size_t>(i) * m + t) * m;
+#pragma unroll
+            for (int r = 0; r < MAXM; ++r)
+                if (r < (int)t) mean[r] += upd[r] * delta;
+            if (t == 0) {
+                fin = true;
+            } else {
+                --t;
 #pragma unroll
                 for (int r = 0; r < MAXM; ++r)
-                    if (r < (int)t) mean[r] += upd[r] * delta;
-                if (t == 0) {
-                    fin = true;
-                } else {
-                    --t;
-#pragma unroll
-                    for (int r = 0; r < MAXM; ++r)
-                        if (r == (int)t) mu = mean[r];
-                    const size_t sv = static_cast<size_t>(i) * m + t;
-                    karney_begin(f, mu, sqrt_var_base[sv], div_base[sv]);
-                }
+                    if (r == (int)t) mu = mean[r];
+                const size_t sv = static_cast<size_t>(i) * m + t;
+                karney_begin(f, mu, sqrt_var_base[sv], div_base[sv]);
             }
-            if ((step & 7) == 0) {
-                const bool take = f.st == KS_DONE && fin;
-                const uint32_t e = wave_take(chunk, take);
-                if (take) {
-                    have = e < chunk.len;
-                    if (have) {
-                        const size_t idx = chunk.base + e;
-                        col = static_cast<uint32_t>(idx >> logN);
-                        i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
-#pragma unroll
-                        for (int r = 0; r < MAXM; ++r)
-                            if (r < (int)m)
-                                mean[r] = c_scale * static_cast<double>(centered_residue(
-                                                        tp2[(((static_cast<size_t>(r) * cols + col) * L) << logN) + i], q0));
-                        rng_reopen(rng, static_cast<uint64_t>(col) + 1, static_cast<uint64_t>(i) + 1);
-                        t = m - 1;
-#pragma unroll
-                        for (int r = 0; r < MAXM; ++r)
-                            if (r == (int)t) mu = mean[r];
-                        fin = false;
-                        const size_t sv = static_cast<size_t>(i) * m + t;
-                        karney_begin(f, mu, sqrt_var_base[sv], div_base[sv]);
-                    } else {
-                        f.st = KS_IDLE;
-                    }
-                }
-                if (__all(f.st == KS_IDLE)) break;
-                rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
-            }
-            karney_heavy(f, rng);
         }
-        karney_light(f, rng);
+    };
+    auto element_done = [&]() {
+        const bool take = f.st == KS_DONE && fin;
+        const uint32_t e = wave_take(chunk, take);
+        if (take) {
+            have = e < chunk.len;
+            if (have) {
+                const size_t idx = chunk.base + e;
+                col = static_cast<uint32_t>(idx >> logN);
+                i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
+#pragma unroll
+                for (int r = 0; r < MAXM; ++r)
+                    if (r < (int)m)
+                        mean[r] = c_scale * static_cast<double>(centered_residue(
+                                                tp2[(((static_cast<size_t>(r) * cols + col) * L) << logN) + i], q0));
+                rng_reopen(rng, static_cast<uint64_t>(col) + 1, static_cast<uint64_t>(i) + 1);
+                t = m - 1;
+#pragma unroll
+                for (int r = 0; r < MAXM; ++r)
+                    if (r == (int)t) mu = mean[r];
+                fin = false;
+                const size_t sv = static_cast<size_t>(i) * m + t;
+                karney_begin(f, mu, sqrt_var_base[sv], div_base[sv]);
+            } else {
+                f.st = KS_IDLE;
+            }
+        }
+    };
+    for (uint32_t step = 0;; step += 8) {
+        integer_ready();
+        element_done();
+        if (__all(f.st == KS_IDLE)) break;
+        rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
+        karney_heavy(f, rng);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
+        integer_ready();
+        karney_heavy(f, rng);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
     }
 }
 
