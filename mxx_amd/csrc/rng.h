@@ -193,8 +193,8 @@ __device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
 // every wanting lane computes its own block (960 instructions for up to 64 blocks).  A lane that runs dry between
 // passes waits (it only consumes draws it holds), so holding passes to every second or third checkpoint trades a few
 // idle lane-steps for whole passes: the kernels choose `scheduled` (G-sampler every third checkpoint - an element
-// starts with block 0's leftover draws -, p1 every second, the Gaussian matrix every one: its elements are one
-// integer long and start empty).
+// starts with block 0's leftover draws -, p1 and the Gaussian matrix every second; the latter, whose one-integer
+// elements start empty, also raises starve_limit out of reach: sampling.hip).
 // `make FILL_POLICY=1` builds the cooperative form instead (measured, not the default:
 // profiles/r03_notes.md): for passes with fewer than 40 wanting lanes the first 16 get a quad
 // each; lane c of the quad holds column c of the requester's state (its counter / nonce words fetched with
@@ -204,10 +204,10 @@ __device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
 #ifndef MXX_FILL_POLICY
 #define MXX_FILL_POLICY 0
 #endif
-__device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool scheduled = true) {
+__device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool scheduled = true, int starve_limit = 16) {
 #if MXX_FILL_POLICY == 0
     const uint32_t avail = rng.tail - rng.head;
-    const bool pass = (scheduled && __any(live && avail <= 20u)) || __popcll(__ballot(live && avail < 6u)) >= 16;
+    const bool pass = (scheduled && __any(live && avail <= 20u)) || __popcll(__ballot(live && avail < 6u)) >= starve_limit;
     if (pass && live && avail <= RNG_BLOCK_DRAWS) rng_block_lane<10>(rng);
 #else
     const uint32_t lane = threadIdx.x & 63u;

@@ -144,8 +144,12 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 // (sub-key shared by all).  Lanes finish at different times, so a lane's store is a lone 8 bytes:
 // it goes to a compact int64 staging array ([poly][N]) that a coalesced pass expands into the L
 // residues per coefficient (storing the residues from here cost a 32-byte HBM write per limb).
-// fill_every = 1, refills at every checkpoint: a coefficient is one integer (~21 draws) and starts with an empty ring, so some lane of
-// the wave is out of draws at every checkpoint whatever the cadence (every 2nd: 2.40 against 2.41 ms on M3A)
+// Refills every second checkpoint and never forced (fill_every = 2, starve limit out of reach): a coefficient is one
+// integer (~21 draws, ~20 steps) and starts with an empty ring, so at EVERY checkpoint about 25 of a wave's 64 lanes are
+// out of draws and the pass - 70 % of this kernel's instructions, counted with a pass at 96 % of the checkpoints -
+// runs whatever the cadence unless the lanes are made to wait.  Waiting costs lane-steps, passes cost ~1000
+// instructions: sampler + scatter + transform of the 20 x 50 matrix 2.82 ms at (1, forced from 16 starving lanes),
+// 2.77 (2, 16), 2.71 (2, never), 2.93 (3, never), 3.30 (4, never).
 __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every) {
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
                 }
             }
             if (__all(f.st == KS_IDLE)) break;
-            rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
+            rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0, 65);  // no forced passes: 64 lanes cannot reach 65
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -222,7 +226,7 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
         MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
                            static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,
-                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 1));
+                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2));
         const hipError_t err = hipGetLastError();
         const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
         ctx_free(ctx, stage);
