@@ -22,7 +22,8 @@
 //     Every comparison is the one the reference makes on 53-bit deviates; the keystream per integer drops from ~19
 //     64-bit words to ~21 draws, i.e. from 2.4 blocks to 0.65.  A 64-bit word (Box-Muller, the offset j of a trial) is
 //     four consecutive draws.  The G-sampler's streams are keyed under ONE sub-key per call (coefficient index moved
-//     from stream2 into stream0), so no kernel on this path carries a per-lane key.
+//     from stream2 into stream0), so no kernel on this path carries a per-lane key.  The Gaussian matrix sampler draws
+//     the two coefficients of a pair from one stream (sampling.hip).
 // Discrete Gaussians use Karney's exact rejection sampler with the reference's
 // iteration caps (cuda/src/matrix/MatrixSampling.cu:30-147): only IEEE double
 // compare / add / mul / div / ceil are involved, so the CPU oracle reproduces the
@@ -193,8 +194,8 @@ __device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
 // every wanting lane computes its own block (960 instructions for up to 64 blocks).  A lane that runs dry between
 // passes waits (it only consumes draws it holds), so holding passes to every second or third checkpoint trades a few
 // idle lane-steps for whole passes: the kernels choose `scheduled` (G-sampler every third checkpoint - an element
-// starts with block 0's leftover draws -, p1 and the Gaussian matrix every second; the latter, whose one-integer
-// elements start empty, also raises starve_limit out of reach: sampling.hip).
+// starts with block 0's leftover draws -, p1 every second, the Gaussian matrix - a pair of coefficients per stream -
+// every third with starve_limit out of reach: sampling.hip).
 // `make FILL_POLICY=1` builds the cooperative form instead (measured, not the default:
 // profiles/r03_notes.md): for passes with fewer than 40 wanting lanes the first 16 get a quad
 // each; lane c of the quad holds column c of the requester's state (its counter / nonce words fetched with

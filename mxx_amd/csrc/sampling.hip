@@ -6,7 +6,7 @@
 // coefficient index and, for the uniform distribution, limb index):
 // sample_distribution_columns therefore equals the matching column slice of the full
 // sample for the same seed (reference: MatrixSampling.cu:232-289, test
-// src/sampler/gpu.rs:323-361).  Gaussian: a ChaCha20 stream per coefficient (Karney's
+// src/sampler/gpu.rs:323-361).  Gaussian: a ChaCha20 stream per pair of coefficients (Karney's
 // sampler takes a variable number of 16-bit draws, rng.h).  Uniform / bit / ternary: fixed-position
 // draws, eight per keystream block (the reference's keying, one stream - i.e. at least
 // one block - per residue, made the generator the whole cost of the call).  Integers are
@@ -139,59 +139,75 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
     }
 }
 
-// discrete Gaussian: persistent lanes (rng.h).  Wave w owns coefficients [w*64*per_lane, +64*per_lane);
-// its lanes take them one at a time (wave_take), each coefficient with its own stream
-// (sub-key shared by all).  Lanes finish at different times, so a lane's store is a lone 8 bytes:
-// it goes to a compact int64 staging array ([poly][N]) that a coalesced pass expands into the L
-// residues per coefficient (storing the residues from here cost a 32-byte HBM write per limb).
-// Refills every second checkpoint and never forced (fill_every = 2, starve limit out of reach): a coefficient is one
-// integer (~21 draws, ~20 steps) and starts with an empty ring, so at EVERY checkpoint about 25 of a wave's 64 lanes are
-// out of draws and the pass - 70 % of this kernel's instructions, counted with a pass at 96 % of the checkpoints -
-// runs whatever the cadence unless the lanes are made to wait.  Waiting costs lane-steps, passes cost ~1000
-// instructions: sampler + scatter + transform of the 20 x 50 matrix 2.82 ms at (1, forced from 16 starving lanes),
-// 2.77 (2, 16), 2.71 (2, never), 2.93 (3, never), 3.30 (4, never).
+// discrete Gaussian: persistent lanes (rng.h).  An element is a PAIR of consecutive coefficients of one polynomial drawn
+// one after the other from ONE stream (gpoly + 1, (i >> 1) + 1) - still a pure function of (seed, global index), column
+// windows commute: the samples depend on no input.  Wave w owns pairs [w*64*per_lane, +64*per_lane); its lanes take
+// them one at a time (wave_take).  Lanes finish at different times, so a lane's store is a lone 8 bytes: it goes to a
+// compact int64 staging array ([poly][N]) that a coalesced pass expands into the L residues per coefficient (storing
+// the residues from here cost a 32-byte HBM write per limb).
+// Why pairs, and the refill policy.  With a stream per coefficient (~21 draws, ~20 steps, an empty ring at every start)
+// about 25 of a wave's 64 lanes were out of draws at EVERY checkpoint and the block pass - counted: 96 % of the
+// checkpoints, 1.74 blocks computed per coefficient for 0.66 consumed, ~70 % of the kernel's instructions - ran whatever
+// the cadence.  A pair's stream lasts ~42 steps and wastes half as many draws, so refills can be held to every third
+// checkpoint and are never forced (a lane that runs dry waits).  Same-box A/B of the group size (M3A call / M4 step):
+// one coefficient per stream 7.60 ms / 0.634, pairs 7.13 / 0.647, quads 7.08 / 0.70 (a small launch lasts as long as
+// its unluckiest lane's chain, which grows with the group), eight 7.2 / -.  Pairs.
+#ifndef GAUSS_GROUP_LOG
+#define GAUSS_GROUP_LOG 1  // two coefficients per stream (the CPU restatement's keying: oracle/oracle_sampling.c)
+#endif
 __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
-                                    double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every) {
+                                    double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every,
+                                    int starve_limit) {
     __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
-    const size_t total = polys << logN;  // polys < 2^32 (checked by the launcher)
-    const size_t N = static_cast<size_t>(1) << logN;
+    const uint32_t glog = logN < GAUSS_GROUP_LOG ? logN : GAUSS_GROUP_LOG;
+    const uint32_t G = 1u << glog;
+    const size_t total = (polys << logN) >> glog;  // groups
     WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
     KarneyFsm f;
     karney_reset(f);
-    bool have = false;
+    bool have = false, fin = true;
+    uint32_t cnt = 0;
     size_t idx = 0;
-    // a superstep = 8 steps: checkpoint (finished coefficient out, next one in, keystream), then twice [service point,
-    // four cheap steps].  Written out instead of `if ((step & 3) == 0)` inside a one-step loop: the compiler then keeps
-    // the state machine in place instead of copying ~30 registers around the branch on every step.
+    auto integer_ready = [&]() {
+        if (f.st == KS_DONE && !fin) {
+            stage[(idx << glog) + cnt] = f.result;
+            ++cnt;
+            if (cnt == G) fin = true;
+            else karney_begin(f, 0.0, sigma, div);
+        }
+    };
     for (uint32_t step = 0;; step += 8) {
+        integer_ready();
         {
-            const bool take = f.st == KS_DONE;  // write the finished coefficient, open the next one's stream
-            if (take && have) stage[idx] = f.result;
+            const bool take = f.st == KS_DONE && fin;
             const uint32_t e = wave_take(chunk, take);
             if (take) {
                 have = e < chunk.len;
                 if (have) {
                     idx = chunk.base + e;
-                    const uint32_t p = static_cast<uint32_t>(idx >> logN);
+                    const uint32_t p = static_cast<uint32_t>(idx >> (logN - glog));
                     const uint32_t row = p / local_ncol, lcol = p - row * local_ncol;
-                    rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx & (N - 1)) + 1);
+                    rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx & ((size_t(1) << (logN - glog)) - 1)) + 1);
+                    cnt = 0;
+                    fin = false;
                     karney_begin(f, 0.0, sigma, div);
                 } else {
                     f.st = KS_IDLE;
                 }
             }
             if (__all(f.st == KS_IDLE)) break;
-            rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0, 65);  // no forced passes: 64 lanes cannot reach 65
+            rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0, starve_limit);
         }
+        karney_heavy(f, rng);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            karney_heavy(f, rng);
+        for (int s = 0; s < 4; ++s) karney_light(f, rng);
+        integer_ready();
+        karney_heavy(f, rng);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) karney_light(f, rng);
-        }
+        for (int s = 0; s < 4; ++s) karney_light(f, rng);
     }
 }
 
@@ -218,15 +234,20 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
     if (dist == GPU_MATRIX_DIST_GAUSS) {
         // enough lanes to fill the chip first, then up to 16 coefficients per lane
         if (polys >> 32) return set_error("gpu_matrix_sample_distribution: too many polynomials");
-        const uint32_t per_lane = sampler_per_lane(total, reinterpret_cast<const void *>(sample_gauss_kernel), ctx->device, ctx->env.sampler_per_lane);
-        const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
+        const size_t groups = total >> (ctx->logN < GAUSS_GROUP_LOG ? ctx->logN : GAUSS_GROUP_LOG);
+        const uint32_t per_lane = sampler_per_lane(groups, reinterpret_cast<const void *>(sample_gauss_kernel), ctx->device, ctx->env.sampler_per_lane);
+        const unsigned blocks = static_cast<unsigned>((groups + 256u * per_lane - 1) / (256u * per_lane));
         const KarneyDivisor div = karney_divisor(sigma);
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
         MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
                            static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,
-                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2));
+                           // one group per lane at most: the call lasts as long as its unluckiest lane's chain, which
+                           // must not wait for keystream - refills at every checkpoint; otherwise every third and
+                           // never forced (64 lanes cannot reach 65)
+                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : (per_lane == 1 ? 1 : 3)),
+                           per_lane == 1 ? 1 : 65);
         const hipError_t err = hipGetLastError();
         const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
         ctx_free(ctx, stage);

@@ -257,7 +257,8 @@ static uint64_t positional_word(const uint64_t *seed, uint64_t s0, uint64_t s2, 
  * Keying as in mxx_amd/csrc/sampling.hip (the reference's, cuda/src/matrix/MatrixSampling.cu:239-289, spends a
  * stream per residue): uniform = positional word of stream (gpoly + 1, 0) under sub-key (tag, limb + 1), rejected
  * words replaced by the first accepted word of the overflow stream (gpoly + 1, i + 1); bit / ternary = the
- * positional word under sub-key (tag, 0); Gaussian = Karney on the coefficient's own stream (gpoly + 1, i + 1). */
+ * positional word under sub-key (tag, 0); Gaussian = Karney integers drawn one after the other from the stream of the
+ * coefficient's pair, (gpoly + 1, (i >> 1) + 1). */
 void orc_sample_distribution(uint64_t *out, size_t rows, size_t local_ncol, size_t full_ncol, size_t col_offset,
                              uint32_t L, uint32_t n, const uint64_t *moduli, int dist, double sigma,
                              const uint64_t *seed) {
@@ -266,6 +267,8 @@ void orc_sample_distribution(uint64_t *out, size_t rows, size_t local_ncol, size
     for (long p = 0; p < total; ++p) {
         size_t row = (size_t)p / local_ncol, lcol = (size_t)p % local_ncol;
         uint64_t gpoly = row * full_ncol + col_offset + lcol;
+        rng_t rg; /* Gaussian: one stream per pair of coefficients, drawn in order */
+        memset(&rg, 0, sizeof(rg));
         for (uint32_t i = 0; i < n; ++i) {
             rng_t r;
             if (dist == 0) {
@@ -282,8 +285,8 @@ void orc_sample_distribution(uint64_t *out, size_t rows, size_t local_ncol, size
             }
             int64_t z;
             if (dist == 1) {
-                rng_init(&r, seed, gpoly + 1, (uint64_t)i + 1, 0, 0x6f70656e66686532ull);
-                z = karney(&r, 0.0, sigma);
+                if ((i & 1u) == 0) rng_init(&rg, seed, gpoly + 1, (uint64_t)(i >> 1) + 1, 0, 0x6f70656e66686532ull);
+                z = karney(&rg, 0.0, sigma);
             } else if (dist == 2) {
                 z = (int64_t)(positional_word(seed, gpoly + 1, 0, 0x6f70656e66686533ull, i) & 1ull);
             } else {
