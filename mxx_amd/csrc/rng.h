@@ -349,19 +349,26 @@ __device__ __forceinline__ double rng_standard_normal(RNG &rng) {
 //   H (Bernoulli e^-1/2): T starts at 1/2 and becomes the last draw; the outcome is the parity of the run length;
 //   B0: T = y, B1: T = (2k+x)/(2k+2) - the two alternating comparisons of B(k, x).
 // A threshold is ceil(T 2^53) split as (hi = top 16 bits, up to 65536 for T = 1; lo = 37 bits); the cheap path
-// compares the draw with hi alone and parks the lane in KS_TIE when they are equal.  T_tag says where T's lo lives
-// if it is ever needed: a constant (1/2, x, (2k+x)/(2k+2)), a deviate whose lo was drawn in an earlier tie (T_lo, or
-// zz_lo for y = z), or a deviate whose lo is still undrawn.
-enum { KS_H = 0, KS_B0, KS_B1, KS_SIGN, KS_TIE, KS_FALLBACK, KS_DONE, KS_IDLE };
-enum { KT_UNDRAWN = 0, KT_HALF, KT_XT, KT_BT, KT_ZZ, KT_OWN };
+// compares the draw with hi alone and parks the lane in KS_TIE when they are equal.
+// State kept small on purpose (the cheap step is ~75 % of these kernels' instructions outside the generator):
+//   st   : KS_H or KS_B for the two kinds of run, else a parked / finished state;
+//   cnt  : continues so far in the current run.  H: its parity is the outcome.  B: the two comparisons alternate, so
+//          cnt even = "z < y" (B0), cnt odd = "r < (2k+x)/(2k+2)" (B1), n = cnt >> 1;
+//   T_hi : top part of the current threshold; zz_hi: top part of B's last z.
+// Where a threshold's low bits live is NOT tracked per step; a tie works it out from (st, cnt): the constants 1/2, x,
+// (2k+x)/(2k+2) at the start of a run / in B1, otherwise the previous deviate - whose low bits exist only if the
+// comparison that drew it tied too, which the tie path records as T_own_cnt / zz_own_cnt (the value of cnt they are
+// valid for; -1 at every run start).
+enum { KS_H = 0, KS_B, KS_SIGN, KS_TIE, KS_FALLBACK, KS_DONE, KS_IDLE };
 
 struct KarneyFsm {
-    int32_t st, k, p_left, b_left, bn, iter, par;
+    int32_t st, k, p_left, b_left, iter;
+    uint32_t cnt;
     bool in_p;
-    uint32_t T_hi, T_tag;      // current threshold
-    uint32_t zz_hi, zz_tag;    // B's last z (KT_UNDRAWN or KT_OWN)
+    uint32_t T_hi, zz_hi;      // current threshold, B's last z (top parts)
     uint32_t xt_hi, bt_hi;     // x and (2k+x)/(2k+2) in ticks of 2^-53, top parts
     uint32_t tie_h, tie_st;    // the draw that tied and the state it tied in
+    uint32_t T_own_cnt, zz_own_cnt;
     uint64_t T_lo, zz_lo, xt_lo, bt_lo;
     double mean, stddev;
     uint64_t cs, magic;  // ceil(stddev) and floor((2^64-1)/cs)
@@ -371,6 +378,7 @@ struct KarneyFsm {
 #define KARNEY_LO_BITS 37
 #define KARNEY_LO_MASK ((1ull << KARNEY_LO_BITS) - 1)
 #define KARNEY_HALF_HI (1u << 15)
+#define KARNEY_NO_OWN 0xffffffffu
 
 // t in [0, 1] -> ceil(t * 2^53)
 __device__ __forceinline__ uint64_t karney_ticks(double t) { return static_cast<uint64_t>(ceil(t * 9007199254740992.0)); }
@@ -394,14 +402,24 @@ __host__ __device__ __forceinline__ KarneyDivisor karney_divisor(double stddev) 
 // once per lane, before the first karney_begin (the select-style transitions read every field)
 __device__ __forceinline__ void karney_reset(KarneyFsm &f) {
     f.st = KS_DONE;
-    f.k = f.p_left = f.b_left = f.bn = f.iter = f.par = 0;
+    f.k = f.p_left = f.b_left = f.iter = 0;
+    f.cnt = 0;
     f.in_p = false;
-    f.T_hi = f.T_tag = f.zz_hi = f.zz_tag = f.xt_hi = f.bt_hi = f.tie_h = f.tie_st = 0;
+    f.T_hi = f.zz_hi = f.xt_hi = f.bt_hi = f.tie_h = f.tie_st = 0;
+    f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
     f.T_lo = f.zz_lo = f.xt_lo = f.bt_lo = 0;
     f.mean = f.stddev = 0.0;
     f.cs = 1;
     f.magic = 0;
     f.result = 0;
+}
+
+// a fresh H run
+__device__ __forceinline__ void karney_open_h(KarneyFsm &f) {
+    f.st = KS_H;
+    f.cnt = 0;
+    f.T_hi = KARNEY_HALF_HI;
+    f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
 }
 
 __device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double stddev, const KarneyDivisor &d) {
@@ -414,10 +432,7 @@ __device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double s
     }
     f.cs = d.cs;
     f.magic = d.magic;
-    f.st = KS_H;
-    f.T_hi = KARNEY_HALF_HI;
-    f.T_tag = KT_HALF;
-    f.par = 0;
+    karney_open_h(f);
     f.k = 0;
     f.in_p = false;
     f.iter = 0;
@@ -427,31 +442,27 @@ __device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double s
 // when they were drawn (KNOWN: the comparison tied)
 template <bool KNOWN>
 __device__ __forceinline__ void karney_advance(KarneyFsm &f, bool lt, uint32_t h, uint64_t lo) {
-    const bool is_h = f.st == KS_H, is_b0 = f.st == KS_B0, is_b1 = f.st == KS_B1;
+    const bool is_b = f.st == KS_B, odd = (f.cnt & 1u) != 0;
+    const bool is_b0 = is_b && !odd, is_b1 = is_b && odd;
     // B's step cap (n > 4096) ends the run as a failed comparison would
-    const bool cont = lt && !(is_b1 && f.bn > 4096);
-    const uint32_t own = KNOWN ? KT_OWN : KT_UNDRAWN;
-    const uint32_t prev_zz_hi = f.zz_hi, prev_zz_tag = f.zz_tag;
-    f.zz_hi = is_b0 ? h : f.zz_hi;
-    f.zz_tag = is_b0 ? own : f.zz_tag;
-    if (KNOWN) {
-        f.zz_lo = is_b0 ? lo : f.zz_lo;
-        f.T_lo = is_h ? lo : f.T_lo;
+    const bool cont = lt && !(is_b1 && (f.cnt >> 1) > 4096u);
+    if (KNOWN) {  // the deviate's low bits exist: remember them for the comparison that may need them
+        if (is_b0) { f.zz_lo = lo; f.zz_own_cnt = f.cnt; }
+        if (!is_b) { f.T_lo = lo; f.T_own_cnt = f.cnt + 1; }
     }
+    const uint32_t zz_prev = f.zz_hi;
+    f.zz_hi = is_b0 ? h : zz_prev;
     if (cont) {
         // H: T = this draw;  B0: T = (2k+x)/(2k+2);  B1: T = y = z
-        f.T_hi = is_h ? h : (is_b0 ? f.bt_hi : prev_zz_hi);
-        f.T_tag = is_h ? own : (is_b0 ? static_cast<uint32_t>(KT_BT) : (prev_zz_tag == KT_OWN ? static_cast<uint32_t>(KT_ZZ) : static_cast<uint32_t>(KT_UNDRAWN)));
-        f.par ^= is_h ? 1 : 0;
-        f.bn += is_b1 ? 1 : 0;
-        f.st = is_h ? KS_H : (is_b0 ? KS_B1 : KS_B0);
+        f.T_hi = is_b ? (odd ? zz_prev : f.bt_hi) : h;
+        f.cnt += 1;
         return;
     }
-    // the run ended: H reports parity-even, B reports n even
-    const bool ok = is_h ? (f.par == 0) : ((f.bn & 1) == 0);
+    // the run ended: H reports an even number of continues, B reports n = cnt >> 1 even
+    const bool ok = ((is_b ? f.cnt >> 1 : f.cnt) & 1u) == 0;
     bool restart = false;
     int32_t next = KS_H;
-    if (is_h) {
+    if (!is_b) {
         if (!f.in_p) {  // G counts consecutive successes, then P needs k(k-1) of them
             const int32_t k2 = f.k + (ok ? 1 : 0);
             const bool g_done = !ok || k2 > 1024;
@@ -470,7 +481,7 @@ __device__ __forceinline__ void karney_advance(KarneyFsm &f, bool lt, uint32_t h
         const int32_t bl = f.b_left - 1;
         f.b_left = bl;
         restart = !ok;
-        next = bl == 0 ? KS_DONE : KS_B0;
+        next = bl == 0 ? KS_DONE : KS_B;
     }
     if (restart) {
         const int32_t it = f.iter + 1;
@@ -481,16 +492,15 @@ __device__ __forceinline__ void karney_advance(KarneyFsm &f, bool lt, uint32_t h
     }
     f.st = next;
     // a fresh H run, or B(k, x) starting over with y = x
+    f.cnt = 0;
     f.T_hi = next == KS_H ? KARNEY_HALF_HI : f.xt_hi;
-    f.T_tag = next == KS_H ? KT_HALF : KT_XT;
-    f.par = 0;
-    f.bn = 0;
+    f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
 }
 
 // one cheap step
 template <typename RNG>
 __device__ __forceinline__ void karney_light(KarneyFsm &f, RNG &rng) {
-    if (f.st > KS_B1 || rng_avail(rng) == 0) return;
+    if (f.st > KS_B || rng_avail(rng) == 0) return;
     const uint32_t h = rng_next16(rng);
     if (h == f.T_hi) {  // one comparison in 65536: the low bits decide, at the next service point
         f.tie_h = h;
@@ -527,10 +537,8 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
             f.iter = it;
             f.k = 0;
             f.in_p = false;
-            f.st = it >= (1 << 16) ? KS_FALLBACK : KS_H;
-            f.T_hi = KARNEY_HALF_HI;
-            f.T_tag = KT_HALF;
-            f.par = 0;
+            karney_open_h(f);
+            if (it >= (1 << 16)) f.st = KS_FALLBACK;
         } else {
             f.b_left = f.k + 1;
             const uint64_t xt = karney_ticks(x);
@@ -540,21 +548,25 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
             f.bt_hi = static_cast<uint32_t>(bt >> KARNEY_LO_BITS);
             f.bt_lo = bt & KARNEY_LO_MASK;
             f.T_hi = f.xt_hi;
-            f.T_tag = KT_XT;
-            f.bn = 0;
+            f.cnt = 0;
+            f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
             f.result = s * (i0 + static_cast<int64_t>(j));
-            f.st = KS_B0;
+            f.st = KS_B;
         }
     } else if (f.st == KS_TIE && rng_avail(rng) >= 6) {
         // the threshold's low bits first (drawn now if it is a deviate that never needed them), then the deviate's
+        const bool is_b = f.tie_st == KS_B, odd = (f.cnt & 1u) != 0;
         uint64_t tlo;
-        switch (f.T_tag) {
-            case KT_HALF: tlo = 0; break;
-            case KT_XT: tlo = f.xt_lo; break;
-            case KT_BT: tlo = f.bt_lo; break;
-            case KT_ZZ: tlo = f.zz_lo; break;
-            case KT_OWN: tlo = f.T_lo; break;
-            default: tlo = karney_draw_lo(rng, f.T_hi); break;
+        if (!is_b) {  // H: 1/2 at the start of the run, then the previous deviate
+            if (f.cnt == 0) tlo = 0;
+            else if (f.T_own_cnt == f.cnt) tlo = f.T_lo;
+            else tlo = karney_draw_lo(rng, f.T_hi);
+        } else if (odd) {  // B1: (2k+x)/(2k+2)
+            tlo = f.bt_lo;
+        } else {  // B0: x at the start of the run, then y = the z of two comparisons ago
+            if (f.cnt == 0) tlo = f.xt_lo;
+            else if (f.zz_own_cnt == f.cnt - 2) tlo = f.zz_lo;
+            else tlo = karney_draw_lo(rng, f.T_hi);
         }
         const uint64_t ulo = karney_draw_lo(rng, f.tie_h);
         f.st = static_cast<int32_t>(f.tie_st);
