@@ -81,6 +81,17 @@ def test_sample_distribution_bit_exact(gpu, oracle, n, depth, bits, base, dist, 
     assert not (gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, code, sigma, seed(gpu, 1)) == m)
 
 
+@pytest.mark.parametrize("sigma", [0.35, 1.0, 2.5, 17.25, 1.0e5, 3.0e7])
+def test_gauss_widths_from_below_one_to_above_the_modulus(gpu, oracle, sigma):
+    """Karney's machine at the edges of its parameter range: ceil(sigma) = 1 (the offset draw is always 0), widths
+    around 1, and widths whose samples wrap around the 24-bit moduli many times (residues of large signed integers)."""
+    p = make_params(gpu, oracle, 256, 2, 24, 12)
+    s = seed(gpu, 41)
+    want = oracle.sample_distribution(3, 2, p.moduli(), 256, "gauss", sigma, s)
+    m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 3, 2, oracle.DIST["gauss"], sigma, s)
+    assert np.array_equal(m.to_coeff_rns(), want)
+
+
 def test_gauss_million_samples_cover_the_tie_path(gpu, oracle):
     """2^20 Gaussian integers, bit for bit: with 16-bit draws about one comparison in 65536 ties and takes the
     low-bits path (KS_TIE on the device, lz_less in the restatement) - a few hundred times here, counted by the oracle."""
