@@ -56,7 +56,15 @@ struct ChaChaRng {
 
 // a lane's ring: 32 slots of 32 bits = 64 draws = two keystream blocks (128 bytes, 32 KB per 256 lanes)
 #define RNG_RING_SLOTS 32
-#define RNG_BLOCK_DRAWS 32u
+#ifndef RNG_DRAW_BITS
+#define RNG_DRAW_BITS 16  // width of a draw: 16 (shipped; the CPU restatement's) or 8 (timing experiments)
+#endif
+#define RNG_DRAW_LOG (RNG_DRAW_BITS == 16 ? 1 : 2)          // log2 of the draws per 32-bit ring slot
+#define RNG_DRAW_MASK ((1u << RNG_DRAW_BITS) - 1u)
+#define RNG_BLOCK_DRAWS (512u / RNG_DRAW_BITS)               // draws per keystream block
+#define RNG_U64_DRAWS (64 / RNG_DRAW_BITS)
+#define RNG_URGENT (RNG_DRAW_BITS == 16 ? 20u : 30u)         // 8 steps + two service points
+#define RNG_STARVING (RNG_DRAW_BITS == 16 ? 6u : 12u)
 
 __host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
@@ -167,7 +175,7 @@ __device__ __forceinline__ void rng_block_lane(ChaChaRng &rng) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = rng.state[i];
     chacha_rounds<UNROLL>(x);
-    const uint32_t slot0 = (rng.tail >> 1) & (RNG_RING_SLOTS - 1);  // 0 or 16
+    const uint32_t slot0 = (rng.tail >> RNG_DRAW_LOG) & (RNG_RING_SLOTS - 1);  // 0 or 16
 #pragma unroll
     for (int i = 0; i < 16; ++i) rng.ring[(slot0 + i) * rng.ring_stride] = x[i] + rng.state[i];
     ++rng.state[12];  // 2^32 blocks = 256 GiB per stream; no stream on this path draws more than a few
@@ -208,7 +216,7 @@ __device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
 __device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool scheduled = true, int starve_limit = 16) {
 #if MXX_FILL_POLICY == 0
     const uint32_t avail = rng.tail - rng.head;
-    const bool pass = (scheduled && __any(live && avail <= 20u)) || __popcll(__ballot(live && avail < 6u)) >= starve_limit;
+    const bool pass = (scheduled && __any(live && avail <= RNG_URGENT)) || __popcll(__ballot(live && avail < RNG_STARVING)) >= starve_limit;
     if (pass && live && avail <= RNG_BLOCK_DRAWS) rng_block_lane<10>(rng);
 #else
     const uint32_t lane = threadIdx.x & 63u;
@@ -223,7 +231,7 @@ __device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool sc
             if (want) rng_block_lane<10>(rng);
             break;
         }
-        if (n < 16 && !__any(live && avail <= 20u)) break;
+        if (n < 16 && !__any(live && avail <= RNG_URGENT)) break;
         // requester with rank r < 16 announces itself to lane 4r (everyone else writes to an odd lane nobody reads)
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mw >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mw), 0u));
         const bool served = want && rank < 16u;
@@ -250,7 +258,7 @@ __device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool sc
         }
         if (req1) {
             uint32_t *dst = rng.ring + (static_cast<int>(req) - static_cast<int>(lane));  // the requester's ring (same wave)
-            const uint32_t slot0 = ((rtail >> 1) & (RNG_RING_SLOTS - 1)) + col;
+            const uint32_t slot0 = ((rtail >> RNG_DRAW_LOG) & (RNG_RING_SLOTS - 1)) + col;
             dst[slot0 * rng.ring_stride] = a + a0;
             dst[(slot0 + 4u) * rng.ring_stride] = b + b0;
             dst[(slot0 + 8u) * rng.ring_stride] = c + c0;
@@ -269,8 +277,8 @@ __device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool sc
 
 // one 16-bit draw (the caller has checked rng_avail)
 __device__ __forceinline__ uint32_t rng_next16(ChaChaRng &rng) {
-    const uint32_t w = rng.ring[((rng.head >> 1) & (RNG_RING_SLOTS - 1)) * rng.ring_stride];
-    const uint32_t v = (rng.head & 1u) ? (w >> 16) : (w & 0xffffu);
+    const uint32_t w = rng.ring[((rng.head >> RNG_DRAW_LOG) & (RNG_RING_SLOTS - 1)) * rng.ring_stride];
+    const uint32_t v = (w >> (RNG_DRAW_BITS * (rng.head & ((1u << RNG_DRAW_LOG) - 1u)))) & RNG_DRAW_MASK;
     ++rng.head;
     return v;
 }
@@ -279,7 +287,7 @@ __device__ __forceinline__ uint32_t rng_next16(ChaChaRng &rng) {
 __device__ __forceinline__ uint64_t rng_next_u64(ChaChaRng &rng) {
     uint64_t v = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v |= static_cast<uint64_t>(rng_next16(rng)) << (16 * i);
+    for (int i = 0; i < RNG_U64_DRAWS; ++i) v |= static_cast<uint64_t>(rng_next16(rng)) << (RNG_DRAW_BITS * i);
     return v;
 }
 
@@ -375,9 +383,9 @@ struct KarneyFsm {
     int64_t result;
 };
 
-#define KARNEY_LO_BITS 37
+#define KARNEY_LO_BITS (53 - RNG_DRAW_BITS)
 #define KARNEY_LO_MASK ((1ull << KARNEY_LO_BITS) - 1)
-#define KARNEY_HALF_HI (1u << 15)
+#define KARNEY_HALF_HI (1u << (RNG_DRAW_BITS - 1))
 #define KARNEY_NO_OWN 0xffffffffu
 
 // t in [0, 1] -> ceil(t * 2^53)
@@ -514,15 +522,18 @@ __device__ __forceinline__ void karney_light(KarneyFsm &f, RNG &rng) {
 // the 37 low bits of a deviate: three draws
 template <typename RNG>
 __device__ __forceinline__ uint64_t karney_draw_lo(RNG &rng, uint32_t hi) {
-    const uint64_t d1 = rng_next16(rng), d2 = rng_next16(rng), d3 = rng_next16(rng);
-    const uint64_t lo = (d1 << 21) | (d2 << 5) | (d3 >> 11);
+    uint64_t bits = 0;  // the smallest whole number of draws that covers the low bits, most significant draw first
+    constexpr int kDraws = (KARNEY_LO_BITS + RNG_DRAW_BITS - 1) / RNG_DRAW_BITS;
+#pragma unroll
+    for (int i = 0; i < kDraws; ++i) bits = (bits << RNG_DRAW_BITS) | rng_next16(rng);
+    const uint64_t lo = bits >> (kDraws * RNG_DRAW_BITS - KARNEY_LO_BITS);
     return (hi == 0 && lo == 0) ? 1 : lo;  // a deviate is never 0
 }
 
 // the expensive transitions; call at wave-convergent service points
 template <typename RNG>
 __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
-    if (f.st == KS_SIGN && rng_avail(rng) >= 5) {
+    if (f.st == KS_SIGN && rng_avail(rng) >= 1 + RNG_U64_DRAWS) {
         const uint32_t w1 = rng_next16(rng);
         const uint64_t w2 = rng_next_u64(rng);
         const int64_t s = (w1 & 1u) ? 1 : -1;
@@ -553,7 +564,7 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
             f.result = s * (i0 + static_cast<int64_t>(j));
             f.st = KS_B;
         }
-    } else if (f.st == KS_TIE && rng_avail(rng) >= 6) {
+    } else if (f.st == KS_TIE && rng_avail(rng) >= 2 * ((KARNEY_LO_BITS + RNG_DRAW_BITS - 1) / RNG_DRAW_BITS)) {
         // the threshold's low bits first (drawn now if it is a deviate that never needed them), then the deviate's
         const bool is_b = f.tie_st == KS_B, odd = (f.cnt & 1u) != 0;
         uint64_t tlo;
@@ -571,7 +582,7 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
         const uint64_t ulo = karney_draw_lo(rng, f.tie_h);
         f.st = static_cast<int32_t>(f.tie_st);
         karney_advance<true>(f, ulo < tlo, f.tie_h, ulo);
-    } else if (f.st == KS_FALLBACK && rng_avail(rng) >= 8) {
+    } else if (f.st == KS_FALLBACK && rng_avail(rng) >= 2 * RNG_U64_DRAWS) {
         f.result = static_cast<int64_t>(llround(f.mean + f.stddev * rng_standard_normal(rng)));
         f.st = KS_DONE;
     }

@@ -329,13 +329,13 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                 if (value >= qt) value %= qt;
                 // block 0 went to pass 1: its unused words are draws 8*dpt..31 of the stream, continue at block 1
                 rng_reopen(rng, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 1);
-                const uint32_t slot0 = (rng.tail >> 1) & (RNG_RING_SLOTS - 1);
+                const uint32_t slot0 = (rng.tail >> RNG_DRAW_LOG) & (RNG_RING_SLOTS - 1);
                 for (uint32_t w = 0; w < nleft; ++w) {
                     const uint64_t lw = left_in[static_cast<size_t>(w) * total + idx];
                     rng.ring[(slot0 + 4 * dpt + 2 * w) * rng.ring_stride] = static_cast<uint32_t>(lw);
                     rng.ring[(slot0 + 4 * dpt + 2 * w + 1) * rng.ring_stride] = static_cast<uint32_t>(lw >> 32);
                 }
-                rng.head = rng.tail + 8 * dpt;
+                rng.head = rng.tail + 2 * RNG_U64_DRAWS * dpt;
                 rng.tail += RNG_BLOCK_DRAWS;
                 double a_last = 0.0;
 #pragma unroll
