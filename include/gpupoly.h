@@ -201,11 +201,13 @@ int gpupoly_matrix_tensor(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix 
  * the row-major layout) instead of a copy_block followed by an add_block; used by the preimage's final assembly
  * (src/sampler/trapdoor/gpu.rs:340-369).  The whole destination takes the operands' format tag.            */
 int gpupoly_matrix_add_rows(GpuMatrix *out, size_t dst_row, const GpuMatrix *lhs, const GpuMatrix *rhs);
-/* out[dst_row .. dst_row + coeff.rows) = NTT(coeff) + addend: `coeff` is a COEFF matrix (left untouched), `addend` an
- * EVAL matrix of the same shape; transform, sum and placement are one pass at n = 2^14 with 32-bit words, three
- * elsewhere.  The preimage's bottom block p2 + z (src/sampler/trapdoor/gpu.rs:340-369) without z's EVAL form ever
- * being written.  The whole destination is tagged EVAL.                                                      */
-int gpupoly_matrix_ntt_add_rows(GpuMatrix *out, size_t dst_row, const GpuMatrix *coeff, const GpuMatrix *addend);
+/* out[dst_row .. dst_row + coeff.rows) = NTT(coeff) + addend: `coeff` is a COEFF matrix, `addend` an EVAL matrix of the
+ * same shape; transform, sum and placement are one pass at n = 2^14 with 32-bit words.  Elsewhere, consume_coeff != 0
+ * (the caller gives `coeff` up: contents and tag unspecified afterwards) lets the library transform it in place and add
+ * in a second pass; with consume_coeff == 0 `coeff` is left untouched at the price of a copy.  The preimage's bottom
+ * block p2 + z (src/sampler/trapdoor/gpu.rs:340-369).  The whole destination is tagged EVAL.               */
+int gpupoly_matrix_ntt_add_rows(GpuMatrix *out, size_t dst_row, GpuMatrix *coeff, const GpuMatrix *addend,
+                                int consume_coeff);
 /* A matrix object over rows [row, row + rows) of m (contiguous in the row-major layout) that SHARES m's storage - an
  * operand without the copy a slice makes.  Destroy it with gpu_matrix_destroy (the storage stays m's) before m.  */
 int gpupoly_matrix_row_view(GpuMatrix *m, size_t row, size_t rows, GpuMatrix **out_view);

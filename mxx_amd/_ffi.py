@@ -112,7 +112,7 @@ SIGNATURES = {
     "gpupoly_matrix_transpose": (C.c_int, [_vp, _vp]),
     "gpupoly_matrix_tensor": (C.c_int, [_vp, _vp, _vp]),
     "gpupoly_matrix_add_rows": (C.c_int, [_vp, C.c_size_t, _vp, _vp]),
-    "gpupoly_matrix_ntt_add_rows": (C.c_int, [_vp, C.c_size_t, _vp, _vp]),
+    "gpupoly_matrix_ntt_add_rows": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_int]),
     "gpupoly_matrix_row_view": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gpupoly_matrix_neg": (C.c_int, [_vp, _vp]),
     "gpupoly_matrix_fill_zero": (C.c_int, [_vp]),

@@ -639,12 +639,15 @@ extern "C" int gpupoly_matrix_add_rows(GpuMatrix *out, size_t dst_row, const Gpu
     ABI_GUARD_END
 }
 
-// Extension: out[dst_row .. dst_row + coeff.rows) = NTT(coeff) + addend.  `coeff` holds coefficients and is left
-// untouched, `addend` is EVAL of the same shape; the transform, the sum and the placement into a row block of a taller
-// matrix are one pass where a fused kernel exists (2^14, 32-bit words: ntt14::fwd_add_kernel), otherwise a copy, a
-// transform in place and an addition.  The preimage's bottom block p2 + z is the caller (mxx_amd/trapdoor.py;
-// src/sampler/trapdoor/gpu.rs:340-369 transforms z, then adds): z's EVAL form is never materialised.
-extern "C" int gpupoly_matrix_ntt_add_rows(GpuMatrix *out, size_t dst_row, const GpuMatrix *coeff, const GpuMatrix *addend) {
+// Extension: out[dst_row .. dst_row + coeff.rows) = NTT(coeff) + addend.  `coeff` holds coefficients, `addend` is EVAL
+// of the same shape; the transform, the sum and the placement into a row block of a taller matrix are one pass where a
+// fused kernel exists (2^14, 32-bit words: ntt14::fwd_add_kernel).  Elsewhere: with consume_coeff != 0 (the caller
+// gives `coeff` up: its contents and format tag are unspecified afterwards) a transform of `coeff` in place and a
+// three-operand sum - the passes the unfused sequence takes -, else a copy, a transform in place and an addition, with
+// `coeff` untouched.  The preimage's bottom block p2 + z is the caller (mxx_amd/trapdoor.py;
+// src/sampler/trapdoor/gpu.rs:340-369 transforms z, then adds): at 2^14 z's EVAL form is never materialised.
+extern "C" int gpupoly_matrix_ntt_add_rows(GpuMatrix *out, size_t dst_row, GpuMatrix *coeff, const GpuMatrix *addend,
+                                           int consume_coeff) {
     ABI_GUARD_BEGIN
     if (!out || !coeff || !addend) return set_error("gpupoly_matrix_ntt_add_rows: null matrix");
     if (matrix_check_same_shape(coeff, addend, "gpupoly_matrix_ntt_add_rows")) return 1;
@@ -667,6 +670,12 @@ extern "C" int gpupoly_matrix_ntt_add_rows(GpuMatrix *out, size_t dst_row, const
         const int rc = launch_ntt_add_u32(ctx, static_cast<uint32_t *>(view.data), static_cast<const uint32_t *>(coeff->data),
                                           static_cast<const uint32_t *>(addend->data), polys * L, static_cast<uint32_t>(L));
         if (rc >= 0) return rc;
+    }
+    if (consume_coeff) {
+        int rc = launch_ntt(ctx, coeff->data, polys * L, static_cast<int>(L), false);
+        if (rc) return rc;
+        coeff->format = GPU_POLY_FORMAT_EVAL;
+        return launch_elementwise<OP_ADD, false>(&view, coeff, addend);
     }
     HIP_TRY(hipMemcpyAsync(view.data, coeff->data, view.bytes, hipMemcpyDeviceToDevice, ctx->stream));
     int rc = launch_ntt(ctx, view.data, polys * L, static_cast<int>(L), false);

@@ -450,13 +450,15 @@ class GpuDCRTPolyMatrix:
         v._finalizer = weakref.finalize(v, _ffi.lib().gpu_matrix_destroy, raw)
         return v
 
-    def ntt_add_rows_from(self, dst_row, coeff, addend) -> None:
+    def ntt_add_rows_from(self, dst_row, coeff, addend, consume: bool = False) -> None:
         """self[dst_row : dst_row + coeff.nrow] = NTT(coeff) + addend (gpupoly_matrix_ntt_add_rows): `coeff` holds
-        coefficients and stays as it is, `addend` is EVAL; one pass where the fused kernel exists."""
+        coefficients, `addend` is EVAL; one pass where the fused kernel exists.  consume: the caller gives `coeff` up
+        (do not use it afterwards) - where no fused kernel exists it is then transformed in place instead of copied."""
         assert coeff.size() == addend.size() and coeff.ncol == self.ncol and dst_row + coeff.nrow <= self.nrow
         assert not coeff.is_ntt, "ntt_add_rows_from takes a coefficient-domain matrix"
         addend = addend.ensure_eval()
-        check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(self.raw, dst_row, coeff.raw, addend.raw), "gpupoly_matrix_ntt_add_rows")
+        st = _ffi.lib().gpupoly_matrix_ntt_add_rows(self.raw, dst_row, coeff.raw, addend.raw, 1 if consume else 0)
+        check_status(st, "gpupoly_matrix_ntt_add_rows")
         self.is_ntt = True
 
     def slice(self, row_start, row_end, col_start, col_end) -> "GpuDCRTPolyMatrix":

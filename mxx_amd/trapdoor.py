@@ -193,7 +193,7 @@ class GpuDCRTPolyTrapdoorSampler:
             # from the output's rows and [R;E] p2 kept from the perturbation step - same residues, and z's
             # evaluation form (the largest matrix of the call) is never written or re-read.
             z = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed(), coeff_out=True)
-            out.ntt_add_rows_from(p1_rows, z, p2)
+            out.ntt_add_rows_from(p1_rows, z, p2, consume=True)
             re_x = td.re * out.row_view(p1_rows, p1_rows + p2_rows)
             out.add_rows_from(0, p1 - tp2, re_x)
             return out

@@ -436,9 +436,13 @@ def test_ntt_add_rows_extension(gpu, oracle, n, depth, bits):
     assert out.is_ntt and np.array_equal(out.to_rns(), want)
     assert not gz.is_ntt and np.array_equal(gz.to_coeff_rns(), z)
     with pytest.raises(gpu.GpuPolyError):  # an EVAL source is refused, and so is a block past the last row
-        _ffi.check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(out.raw, 1, ga.raw, ga.raw), "gpupoly_matrix_ntt_add_rows")
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(out.raw, 1, ga.raw, ga.raw, 0), "gpupoly_matrix_ntt_add_rows")
     with pytest.raises(gpu.GpuPolyError):
-        _ffi.check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(out.raw, 3, gz.raw, ga.raw), "gpupoly_matrix_ntt_add_rows")
+        _ffi.check_status(_ffi.lib().gpupoly_matrix_ntt_add_rows(out.raw, 3, gz.raw, ga.raw, 0), "gpupoly_matrix_ntt_add_rows")
+    # the consuming form (the source may be transformed in place where no fused kernel exists): same result
+    out2 = gpu.GpuDCRTPolyMatrix.from_rns(p, base, True)
+    out2.ntt_add_rows_from(1, gz, ga, consume=True)
+    assert np.array_equal(out2.to_rns(), want)
 
 
 def test_row_view_extension(gpu, oracle):
