@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 // +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
 template <typename W, int MAXD>
-__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ src,
+__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage,
                                         const LimbConst *__restrict__ limbs, ChaChaKey key,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
     bool fin = true, have = false;
     uint32_t ph = 0;
     size_t idx = 0;
-    uint64_t qt = 1, value = 0;
+    uint64_t qt = 1;
     double a[MAXD];
     int64_t z[MAXD];
     int64_t z_last = 0;
@@ -299,20 +299,10 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
     auto element_done = [&]() {  // element complete: write its digits, take the next one
         const bool take = f.st == KS_DONE && fin;  // element complete: write its digits, take the next one
         if (take && have) {
-            int64_t z_prev = 0;
 #pragma unroll
             for (int d = 0; d < MAXD; ++d) {
                 if (d < (int)dpt) {
-                    const int64_t md = static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1));
-                    const int64_t vd = static_cast<int64_t>((value >> (base_bits * d)) & (base - 1));
-                    const int64_t zd = d < last ? z[d] : z_last;
-                    int64_t digit;
-                    if (dpt == 1) digit = static_cast<int64_t>(base) * zd + md * zd + vd;
-                    else if (d == 0) digit = static_cast<int64_t>(base) * zd + md * z_last + vd;
-                    else if (d < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
-                    else digit = md * z_last - z_prev + vd;
-                    z_prev = zd;
-                    stage[idx * dpt + d] = digit;
+                    stage[idx * dpt + d] = d < last ? z[d] : z_last;  // pass 3 turns the integers into digits
                 }
             }
         }
@@ -325,8 +315,6 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                 const uint32_t pt = static_cast<uint32_t>(idx >> logN);
                 const uint32_t p = pt / L, t = pt - p * L;
                 qt = limbs[t].q;
-                value = static_cast<uint64_t>(src[idx]);
-                if (value >= qt) value %= qt;
                 // block 0 went to pass 1: its unused words are draws 8*dpt..31 of the stream, continue at block 1
                 rng_reopen(rng, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 1);
                 const uint32_t slot0 = (rng.tail >> RNG_DRAW_LOG) & (RNG_RING_SLOTS - 1);
@@ -369,21 +357,37 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
     }
 }
 
-// Pass 3, coalesced: digit (p, t, i, d) -> residues in every limb of output row r*k + t*dpt + d.
-// (Pass 2's lanes finish at different times; storing L residues per digit from there made every
-// store a lone 32-byte HBM write - 6x the algorithmic bytes.)
+// Pass 3, coalesced: the dpt integers of element (p, t, i) -> its digits -> residues in every limb of output rows
+// r*k + t*dpt + d.  (Pass 2's lanes finish at different times; storing L residues per digit from there made every
+// store a lone 32-byte HBM write - 6x the algorithmic bytes.  The digit arithmetic lives here too: this pass is
+// bound by its stores, pass 2 by its instruction count - lanes kernel 2.56 -> 2.47 ms.)
 template <typename W>
 __global__ void __launch_bounds__(256) gauss_samp_expand_kernel(W *__restrict__ out, const int64_t *__restrict__ stage,
-                                         const LimbConst *__restrict__ limbs, size_t total, uint32_t src_cols, uint32_t L,
-                                         uint32_t logN, uint32_t dpt, uint32_t k) {
+                                         const W *__restrict__ src, const LimbConst *__restrict__ limbs, size_t total,
+                                         uint32_t src_cols, uint32_t L, uint32_t logN, uint32_t dpt, uint32_t k,
+                                         uint32_t base_bits) {
     const size_t idx = item_index();
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
     const uint32_t pt = static_cast<uint32_t>(idx >> logN);
     const uint32_t p = pt / L, t = pt - p * L;
     const uint32_t r = p / src_cols, col = p - r * src_cols;
+    const uint64_t qt = limbs[t].q, base = 1ull << base_bits;
+    uint64_t value = static_cast<uint64_t>(src[idx]);
+    if (value >= qt) value %= qt;
+    const int last = static_cast<int>(dpt) - 1;
+    const int64_t z_last = stage[idx * dpt + last];
+    int64_t z_prev = 0;
     for (uint32_t d = 0; d < dpt; ++d) {
-        const int64_t digit = stage[idx * dpt + d];
+        const int64_t md = static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1));
+        const int64_t vd = static_cast<int64_t>((value >> (base_bits * d)) & (base - 1));
+        const int64_t zd = stage[idx * dpt + d];
+        int64_t digit;
+        if (dpt == 1) digit = static_cast<int64_t>(base) * zd + md * zd + vd;
+        else if (d == 0) digit = static_cast<int64_t>(base) * zd + md * z_last + vd;
+        else if (static_cast<int>(d) < last) digit = static_cast<int64_t>(base) * zd - z_prev + md * z_last + vd;
+        else digit = md * z_last - z_prev + vd;
+        z_prev = zd;
         const size_t orow = static_cast<size_t>(r) * k + t * dpt + d;
         W *dst = out + (((orow * src_cols + col) * L) << logN) + i;
         for (uint32_t l = 0; l < L; ++l)
@@ -416,13 +420,13 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
     const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
-                       static_cast<int64_t *>(stage), src, ctx->d_limbs, key,
+                       static_cast<int64_t *>(stage), ctx->d_limbs, key,
                        static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
                        base_bits, c, karney_divisor(sigma), per_lane,
                        static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3));
     MXX_LAUNCH(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
-                       ctx->stream, out, static_cast<const int64_t *>(stage), ctx->d_limbs, total, src_cols, L, ctx->logN,
-                       dpt, static_cast<uint32_t>(k));
+                       ctx->stream, out, static_cast<const int64_t *>(stage), src, ctx->d_limbs, total, src_cols, L, ctx->logN,
+                       dpt, static_cast<uint32_t>(k), base_bits);
     const hipError_t err = hipGetLastError();
     ctx_free(ctx, towers);
     ctx_free(ctx, a_buf);
