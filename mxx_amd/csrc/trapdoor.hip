@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(128) gauss_samp_gq_kernel(W *__restrict__ out,
 struct GqTower {
     double c_last, sd;
     KarneyDivisor div;
+    double cvec[4];  // c_d of the tower's modulus digits (the lane kernel handles at most four digits per tower)
 };
 
 __global__ void gq_tower_kernel(GqTower *__restrict__ towers, const LimbConst *__restrict__ limbs, uint32_t L,
@@ -165,9 +166,12 @@ __global__ void gq_tower_kernel(GqTower *__restrict__ towers, const LimbConst *_
     const double sigma = c / (base_f + 1.0);
     const uint64_t qt = limbs[t].q;
     double c_last = 0.0;
-    for (uint32_t d = 0; d < dpt; ++d)
-        c_last = (c_last + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
     GqTower g;
+    for (uint32_t d = 0; d < 4; ++d) g.cvec[d] = 0.0;
+    for (uint32_t d = 0; d < dpt; ++d) {
+        c_last = (c_last + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
+        if (d < 4) g.cvec[d] = c_last;
+    }
     g.c_last = c_last;
     g.sd = sigma / c_last;
     g.div = karney_divisor(g.sd);
@@ -256,7 +260,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
     bool fin = true, have = false;
     uint32_t ph = 0;
     size_t idx = 0;
-    uint64_t qt = 1;
+    uint32_t tower = 0;
     double a[MAXD];
     int64_t z[MAXD];
     int64_t z_last = 0;
@@ -270,15 +274,10 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
         if (f.st == KS_DONE && !fin) {  // an integer of the current element is ready
             if (ph == 0) {
                 z_last = f.result;
-                double prev_c = 0.0;
+                const double zl = static_cast<double>(z_last);
 #pragma unroll
-                for (int d = 0; d < MAXD; ++d) {
-                    if (d < (int)dpt) {
-                        const double cd = (prev_c + static_cast<double>(static_cast<int64_t>((qt >> (base_bits * d)) & (base - 1)))) / base_f;
-                        prev_c = cd;
-                        a[d] += static_cast<double>(z_last) * cd;
-                    }
-                }
+                for (int d = 0; d < MAXD; ++d)
+                    if (d < (int)dpt) a[d] += zl * towers[tower].cvec[d];  // c_d: per tower, from gq_tower_kernel
             } else {
 #pragma unroll
                 for (int d = 0; d < MAXD; ++d)
@@ -314,7 +313,7 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
                 const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
                 const uint32_t pt = static_cast<uint32_t>(idx >> logN);
                 const uint32_t p = pt / L, t = pt - p * L;
-                qt = limbs[t].q;
+                tower = t;
                 // block 0 went to pass 1: its unused words are draws 8*dpt..31 of the stream, continue at block 1
                 rng_reopen(rng, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 1);
                 const uint32_t slot0 = (rng.tail >> RNG_DRAW_LOG) & (RNG_RING_SLOTS - 1);
