@@ -118,6 +118,36 @@ def test_gauss_persistent_lanes_bit_exact(gpu, oracle, hip_env, per_lane, n, row
     assert np.array_equal(m.to_coeff_rns(), want)
 
 
+@pytest.mark.parametrize("fill_every,per_lane", [("1", "2"), ("5", "7"), ("8", "3")])
+def test_samples_do_not_depend_on_the_refill_cadence(gpu, oracle, hip_env, fill_every, per_lane):
+    """The lane kernels' keystream refills are scheduled every k-th checkpoint and a lane that runs dry waits; a sample
+    is a function of its stream alone, so the Gaussian matrix, the G-sampler's digits and a whole preimage stay
+    bit-identical to the CPU restatement under any cadence and any number of elements per lane."""
+    from mxx_amd.sampler import seed_source
+
+    hip_env.set("MXX_HIP_SAMPLER_FILL_EVERY", fill_every)
+    hip_env.set("MXX_HIP_SAMPLER_PER_LANE", per_lane)
+    n, depth, bits, base = 1024, 2, 24, 12
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    s = seed(gpu, 12)
+    m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, oracle.DIST["gauss"], 321.7, s)
+    assert np.array_equal(m.to_coeff_rns(), oracle.sample_distribution(2, 3, moduli, n, "gauss", 321.7, s))
+    M = rand_matrix(oracle, 91, 2, 2, moduli, n)
+    c = ((1 << base) + 1) * 4.578
+    z = gpu.GpuDCRTPolyMatrix.from_rns(p, M, False).gauss_samp_gq_arb_base(c, 4.578, s).to_coeff_rns()
+    assert np.array_equal(z, oracle.gauss_samp_gq(M, moduli, base, c, s))
+    master = bytes(range(32))
+    seeds = [oracle._seed_from(master, i).tobytes() for i in range(6)]
+    r, e, a = oracle.trapdoor_gen(moduli, n, base, 4.578, 1, master)
+    target = oracle.matrix_ntt(rand_matrix(oracle, 78, 1, 2, moduli, n), moduli)
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, 4.578)
+    with seed_source(seeds):
+        td, A = sampler.trapdoor(p, 1)
+        x = sampler.preimage(p, td, A, gpu.GpuDCRTPolyMatrix.from_rns(p, target, True))
+    assert np.array_equal(x.ensure_eval().to_rns(), oracle.preimage(moduli, n, base, 4.578, r, e, a, target, master))
+
+
 @pytest.mark.parametrize("per_lane", ["1", "5"])
 @pytest.mark.parametrize("n,depth,bits,base", [(1024, 2, 24, 12), (128, 2, 17, 6), (64, 2, 51, 17), (128, 2, 16, 16)])
 def test_gauss_samp_gq_lane_form_equals_simple_form(gpu, oracle, hip_env, per_lane, n, depth, bits, base):
