@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m3a", "m3b", "m4"])
+    ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m2b_decompose", "m2b_mul_decompose", "m3a", "m3b", "m4"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--gather", default="step", choices=["lazy", "step"],
                     help="sharded runs: all-gather the column blocks (product, preimage) after every step, overlapped with the "
@@ -60,7 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--inproc", action="store_true",
                     help="N>1 in ONE process, as the reference runs (a context per device, a worker thread per context, the "
                          "exchange through gpupoly_matrix_all_gather_columns - RCCL behind the C ABI, no torch)")
-    ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K steps for median / min")
+    ap.add_argument("--repeats", type=int, default=10, help="extra repetitions of the K steps for median / min")
+    ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel launch trace (composed rooflines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per block")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -181,6 +182,20 @@ class Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min_over_ranks(self, value: float) -> float:
+        if not self.active:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def gather_objects(self, obj):
+        if not self.active:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def finish(self):
         if self.active:
             self.dist.barrier()
@@ -202,6 +217,15 @@ def uniform_matrix(mx, params, rows, cols, tag, total_cols=None, col_start=0):
         return mx.GpuDCRTPolyMatrix.sample_distribution(params, rows, cols, code, 0.0, fixed_seed(mx, tag))
     return mx.GpuDCRTPolyMatrix.sample_distribution_columns(params, rows, total_cols, col_start, cols, code, 0.0,
                                                              fixed_seed(mx, tag))
+
+
+def inject_fault(full):
+    """Test hook (tests/test_gpu_comm.py): MXX_BENCH_FAULT_INJECT=shift hands the self-validation a gathered matrix whose
+    columns are rotated by one - what a wrong peer offset in the exchange would produce - so that the suite can prove the
+    bench fails on it.  Unset (always, outside that test): the matrix itself."""
+    if os.environ.get("MXX_BENCH_FAULT_INJECT") != "shift" or full.ncol < 2:
+        return full
+    return full.slice_columns(1, full.ncol).concat_columns([full.slice_columns(0, 1)])
 
 
 class Workload:
@@ -440,12 +464,20 @@ class MatMul(Workload):
         if col is not None:
             one = self.a * col
             assert one == self.out.slice_columns(0, 1), "product column differs between kernel paths"
-        if self.strong and self.full is not None and self.c_local:  # the gathered matrix holds this rank's block where it belongs
-            from mxx_amd.parallel import shard_range
+        if self.strong and self.full is not None:
+            # self-validation of the exchange: EVERY rank recomputes the WHOLE product - B is a pure
+            # function of (seed, global column), so the foreign blocks are recomputable here - and compares it with the
+            # gathered matrix: a wrong peer offset, a missed event wait or a stride bug in the gather cannot pass
+            from mxx_amd.parallel import blocks_that_differ
 
-            sr = shard_range(self.shape[2], self.d.world, self.d.rank)
-            assert self.full.ncol == self.shape[2], "gathered product has the wrong width"
-            assert self.full.slice_columns(sr.start, sr.stop) == self.out, "gathered product block differs"
+            r, k, c = self.shape
+            assert self.full.ncol == c, "gathered product has the wrong width"
+            whole = self.a * uniform_matrix(self.mx, self.params, k, c, 5)
+            full = inject_fault(self.full)
+            bad = blocks_that_differ(c, self.d.world, lambda lo, hi: full.slice_columns(lo, hi) == whole.slice_columns(lo, hi))
+            if bad:
+                raise AssertionError(f"rank {self.d.rank}: gathered product differs from the recomputed one in the blocks of ranks {bad}")
+            self.foreign_blocks_checked = self.d.world - 1
 
 
 
@@ -457,6 +489,75 @@ class M2A(MatMul):
 class M2B(MatMul):
     name, depth, shape = "m2b", 8, (64, 64, 64)
     kernel_label = "R_q matrix product (fat)"
+
+
+class M2BDecompose(Workload):
+    """BASELINE configs[2], second half: G^-1 of a 64 x 64 matrix over R_q (n=2^14, L=8, base 2^12 -> k = 16 digits per
+    entry): EVAL in, the 1024 x 64 digit matrix in EVAL form out (34.4 GB, written once).  The reference wrapper's
+    `decompose` (src/matrix/gpu_dcrt_poly.rs:315-341: clone, INTT, gpu_matrix_decompose_base into an EVAL output)."""
+
+    name, depth = "m2b_decompose", 8
+
+    def setup(self):
+        mx, p = self.mx, self.params
+        self.m = uniform_matrix(mx, p, 64, 64, 6)
+        self.k = p.modulus_digits()
+        self.units = 64 * 64 * self.d.world  # ring elements decomposed per step (independent per rank)
+        # SURVEY 8d: (r c + r k c) n L w - the source read once, the digit matrix written once
+        self.algo = float(64 * 64 + 64 * self.k * 64) * N_RING * self.depth * self.word
+        self.kernels = (("decompose call (copy + INTT of the source, digits inside the forward transform's load)", self.algo),)
+        self.nmarks = 2
+        self.metric, self.unit = "ring_elements_decomposed_per_s", "ring-elements/s"
+        self.desc = (f"M2B decompose (BASELINE configs[2]): n=2^14, L={self.depth} (24-bit), base 2^12, G^-1 of a 64x64 matrix -> "
+                     f"{64 * self.k}x64 digit polynomials in EVAL form")
+        self.sharding = "independent matrices per rank, no collective" if self.d.world > 1 else "single GPU"
+        self.out = None
+
+    def step(self, i, mark):
+        if mark:
+            self.mark(i, 0)
+        self.out = None  # the previous step's 34 GB go back to the stream-ordered cache before the next allocation
+        self.out = self.m.decompose()
+        if mark:
+            self.mark(i, 1)
+
+    def check(self):
+        g = self.mx.GpuDCRTPolyMatrix.gadget_matrix(self.params, 64)
+        assert g * self.out == self.m, "G * G^-1(M) != M"
+
+
+class M2BMulDecompose(Workload):
+    """The fused consumer of the same decomposition: S * G^-1(B), S 8 x 1024, B 64 x 64 - one ABI
+    call (gpupoly_matrix_mul_decompose) where the reference's wrapper loops over columns (gpu_dcrt_poly.rs:1414-1493)."""
+
+    name, depth = "m2b_mul_decompose", 8
+
+    def setup(self):
+        mx, p = self.mx, self.params
+        self.k = p.modulus_digits()
+        self.b = uniform_matrix(mx, p, 64, 64, 6)
+        self.s = uniform_matrix(mx, p, 8, 64 * self.k, 7)
+        self.units = 8 * 64 * self.k * 64 * self.d.world  # ring multiply-accumulates per step
+        # operands and result only: the digit matrix is internal to the call (its 34.4 GB are what a fusion that never
+        # materialised it would save; the composed roofline below prices the kernels that actually run)
+        self.algo = float(8 * 64 * self.k + 64 * 64 + 8 * 64) * N_RING * self.depth * self.word
+        self.kernels = (("mul_decompose call (digit transform + product)", self.algo),)
+        self.nmarks = 2
+        self.desc = (f"M2B mul_decompose: n=2^14, L={self.depth}, (8x{64 * self.k}) * G^-1(64x64), one ABI call; "
+                     "1 ring-op = one R_q multiply-accumulate")
+        self.sharding = "independent products per rank, no collective" if self.d.world > 1 else "single GPU"
+        self.out = None
+
+    def step(self, i, mark):
+        if mark:
+            self.mark(i, 0)
+        self.out = None
+        self.out = self.s.mul_decompose(self.b)
+        if mark:
+            self.mark(i, 1)
+
+    def check(self):
+        assert self.out == self.s * self.b.decompose(), "S * G^-1(B) differs from the two-step form"
 
 
 class Preimage(Workload):
@@ -532,12 +633,23 @@ class Preimage(Workload):
     def check(self):
         if self.c_local:
             assert self.pub * self.x == self.target, "A*x != u"
-        if self.strong and self.full is not None and self.c_local:
-            from mxx_amd.parallel import shard_range
+        if self.strong and self.full is not None:
+            # self-validation of the exchange: the preimages are freshly randomised per call, so a foreign block cannot be
+            # recomputed - but the trapdoor is replicated and the target is a pure function of (seed, global column), so
+            # EVERY rank checks A * x = u over ALL gathered columns, and its own block bit for bit
+            from mxx_amd.parallel import blocks_that_differ, shard_range
 
-            sr = shard_range(self.cols, self.d.world, self.d.rank)
             assert self.full.ncol == self.cols, "gathered preimage has the wrong width"
-            assert self.full.slice_columns(sr.start, sr.stop) == self.x, "gathered preimage block differs"
+            whole_target = uniform_matrix(self.mx, self.params, self.dsize, self.cols, 9)
+            full = inject_fault(self.full)
+            img = self.pub * full
+            bad = blocks_that_differ(self.cols, self.d.world, lambda lo, hi: img.slice_columns(lo, hi) == whole_target.slice_columns(lo, hi))
+            if bad:
+                raise AssertionError(f"rank {self.d.rank}: A * x != u in the gathered blocks of ranks {bad}")
+            sr = shard_range(self.cols, self.d.world, self.d.rank)
+            if self.c_local:
+                assert full.slice_columns(sr.start, sr.stop) == self.x, "gathered preimage block differs from the local one"
+            self.foreign_blocks_checked = self.d.world - 1
 
 
 class M3A(Preimage):
@@ -600,7 +712,8 @@ class M4(Workload):
         assert self.mx.GpuDCRTPolyMatrix.gadget_matrix(self.params, self.dd) * self.mmat.decompose() == self.mmat
 
 
-WORKLOADS = {"m1": M1, "m2a": M2A, "m2b": M2B, "m3a": M3A, "m3b": M3B, "m4": M4}
+WORKLOADS = {"m1": M1, "m2a": M2A, "m2b": M2B, "m2b_decompose": M2BDecompose, "m2b_mul_decompose": M2BMulDecompose,
+             "m3a": M3A, "m3b": M3B, "m4": M4}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -620,6 +733,7 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
         # once outside the clock - its first use is set-up, not throughput
         wl.step(0, False)
     wl.drain()
+    wl.ctx.marker(1)  # delimits the timed region in a profiler's dispatch list (tools/pmc_window.py); outside the clock
     d.barrier_sync(mx.gpu_device_sync)
     t0 = time.perf_counter()
     for i in range(steps):
@@ -627,6 +741,7 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
     wl.drain()
     d.barrier_sync(mx.gpu_device_sync)
     elapsed = d.max_over_ranks(time.perf_counter() - t0)
+    wl.ctx.marker(2)
     kernel_ms = wl.kernel_ms(steps)
     reps = []
     for _ in range(repeats):
@@ -655,7 +770,18 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
         wl.lazy_gather = not wl.lazy_gather
         wl.step(0, False)
         wl.drain()
-    wl.check()
+    # every rank validates (its own block and every gathered foreign block); the verdict is collective so that one rank's
+    # failure fails the whole job instead of leaving the others in the next barrier
+    failure = None
+    try:
+        wl.check()
+    except AssertionError as e:
+        failure = e
+    all_ok = d.min_over_ranks(0.0 if failure else 1.0)
+    if failure is not None:
+        raise failure
+    if all_ok < 1.0:
+        raise AssertionError(f"rank {d.rank}: another rank's self-validation failed")
     all_ms = [elapsed * 1e3 / steps] + reps
     return {
         "other_gather": other,
@@ -680,20 +806,116 @@ def roofline_of(wl: Workload, kernel_ms):
     label = getattr(wl, "launched_kernel", None) or label
     achieved = algo / (ms * 1e-3) / 1e9
     traffic = source = None
-    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{wl.name}.json")
-    if os.path.exists(tpath) and wl.d.world == 1:
-        try:
-            rec = json.load(open(tpath))
-            traffic = rec.get("hbm_bytes_per_launch")
-            # PMC counters need their own rocprofv3 passes (the guide's HBM section): the figure is read from the committed
-            # summary of the same command, not measured in this run
-            source = f"profiles/pmc_traffic_{wl.name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload {wl.name}`, " \
-                     f"kernel {rec.get('kernel', '?')})"
-        except Exception:
-            traffic = source = None
+    # PMC counters need their own rocprofv3 passes (the guide's HBM section): the figure is read from the committed record
+    # of the same command (tools/collect_r04.sh -> tools/pmc_window.py: only the launches between bench.py's region markers
+    # are counted, FETCH_SIZE doubled as the guide prescribes for gfx950), not measured in this run
+    rec = load_profile_json(f"r04_pmc_{wl.name}.json") if wl.d.world == 1 else None
+    krec = (rec or {}).get("kernels", {}).get(kernel_base(label))
+    if krec and krec.get("hbm_bytes_per_launch"):
+        traffic = krec["hbm_bytes_per_launch"]
+        source = f"profiles/r04_pmc_{wl.name}.json ({rec.get('source', 'rocprofv3 --pmc passes')}; kernel {kernel_base(label)}, " \
+                 f"{krec.get('launches_per_step')} launch(es) per step)"
     return {"bound": "hbm", "kernel": label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
             "algorithmic_bytes_per_launch": algo, "kernel_ms": round(ms, 5)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# composed roofline of a multi-kernel call (a preimage, a decomposition, a chain step)
+# ---------------------------------------------------------------------------------------------------
+SIMDS = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4          # peak engine clock (MI355X_MICROARCH.md); the chip holds less under load, so issue floors are optimistic
+DEFAULT_VALU_CYCLES = 4.0  # a wave64 VALU instruction on a 16-lane SIMD; per-kernel prices from the ISA mix where known
+
+
+def kernel_base(name: str) -> str:
+    """`void ntt14::fwd_kernel<unsigned int, false>(unsigned int*, ...)` / `(ntt14::fwd_kernel<W, TIGHT>)` -> `ntt14::fwd_kernel`"""
+    s = name.strip().strip("()").strip()
+    if s.startswith("void "):
+        s = s[5:]
+    for ch in "<(":
+        k = s.find(ch)
+        if k > 0:
+            s = s[:k]
+    return s.strip()
+
+
+def traced_kernels(wl: Workload, steps: int = 3):
+    """Per-kernel hipEvent durations of `steps` steps of the workload: the library brackets every launch (and device copy)
+    with two events on the stream it is enqueued on (gpupoly_trace_begin / _end).  Returns {kernel: {launches, ms, bytes}}
+    per STEP, kernels in first-launch order."""
+    from mxx_amd import _ffi
+
+    wl.step(0, False)
+    wl.drain()
+    wl.mx.gpu_device_sync()
+    _ffi.trace_begin()
+    try:
+        for i in range(steps):
+            wl.step(i, False)
+        wl.drain()
+        wl.mx.gpu_device_sync()
+    finally:
+        entries = _ffi.trace_end()
+    agg = {}
+    for e in entries:
+        a = agg.setdefault(kernel_base(e["kernel"]), {"launches": 0.0, "ms": 0.0, "bytes": 0.0})
+        a["launches"] += 1.0 / steps
+        a["ms"] += e["ms"] / steps
+        a["bytes"] += e["bytes"] / steps
+    return agg
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def composed_roofline(wl: Workload, call_ms: float, steps: int = 3):
+    """roofline of a call that is a SEQUENCE of kernels: per kernel the larger of its HBM byte floor (stated algorithmic
+    bytes of its operands at the 8 TB/s peak) and its VALU issue floor (wave-level VALU instructions, counted by a committed
+    rocprofv3 --pmc SQ_INSTS_VALU pass of this workload, at the ISA mix's cycles per instruction on 1024 SIMDs at 2.4 GHz);
+    frac = sum of the floors / the untraced call time.  Durations per kernel are measured HERE with hipEvents."""
+    agg = traced_kernels(wl, steps)
+    pmc = load_profile_json(f"r04_pmc_{wl.name}.json") or {}
+    mix = (load_profile_json("r04_valu_mix.json") or {}).get("kernels", {})
+    pk = pmc.get("kernels", {})
+    rows, floor_sum, byte_sum, byte_floor_sum, traced_ms = [], 0.0, 0.0, 0.0, 0.0
+    for base, a in agg.items():
+        byte_ms = a["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3
+        rec = pk.get(base)
+        valu = issue_ms = price = None
+        if rec and rec.get("launches_per_step"):
+            # the counted step and the traced step launch the same kernels; scale if the launch counts differ (other column count)
+            valu = rec["SQ_INSTS_VALU"] * (a["launches"] / rec["launches_per_step"])
+            price = (mix.get(base) or {}).get("cycles_per_inst", DEFAULT_VALU_CYCLES)
+            issue_ms = valu * price / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+        floor = max(byte_ms, issue_ms or 0.0)
+        floor_sum += floor
+        byte_sum += a["bytes"]
+        byte_floor_sum += byte_ms
+        traced_ms += a["ms"]
+        rows.append({"kernel": base, "launches": round(a["launches"], 2), "ms": round(a["ms"], 4),
+                     "algorithmic_bytes": a["bytes"] or None, "byte_floor_ms": round(byte_ms, 4),
+                     "SQ_INSTS_VALU": round(valu) if valu else None, "cycles_per_inst": price,
+                     "issue_floor_ms": round(issue_ms, 4) if issue_ms is not None else None,
+                     "bound": "valu" if (issue_ms or 0.0) > byte_ms else "hbm",
+                     "frac": round(floor / a["ms"], 4) if a["ms"] > 0 else None})
+    rows.sort(key=lambda r_: -r_["ms"])
+    achieved = byte_sum / (call_ms * 1e-3) / 1e9
+    return {"bound": "composed: per kernel max(HBM byte floor at 8 TB/s, VALU issue floor at the ISA mix's price on 1024 SIMDs x 2.4 GHz)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(floor_sum / call_ms, 4), "frac_hbm_bytes_only": round(byte_floor_sum / call_ms, 4),
+            "traffic": pmc.get("hbm_bytes_per_step"),
+            "traffic_source": pmc.get("source"),
+            "algorithmic_bytes_per_call": byte_sum, "call_ms": round(call_ms, 4),
+            "sum_of_kernel_ms_traced": round(traced_ms, 4), "sum_of_floors_ms": round(floor_sum, 4),
+            "valu_counts_source": pmc.get("source") if pk else None,
+            "kernels": rows[:14], "kernels_not_listed": max(0, len(rows) - 14)}
 
 
 def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
@@ -721,6 +943,8 @@ def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
         "repeats": res["repeats"],
         "roofline": roofline_of(wl, res["kernel_ms"]),
         **({"kernel_launches_per_step": int(wl.launches_per_step)} if hasattr(wl, "launches_per_step") else {}),
+        **({"exchange": torch_exchange_report(wl, d)} if d.active and not d.inproc and getattr(wl, "strong", False)
+           and isinstance(wl, (MatMul, Preimage)) else {}),
     }
 
 
@@ -734,12 +958,54 @@ def kernels_block(m1: Workload, res):
     (fl, fa), (gl, ga) = m1.kernels
     out["ntt_forward"] = entry(fl, res["kernel_ms"][0], fa)
     out["mul_intt_fused"] = entry(gl, res["kernel_ms"][1], ga)
+    rec = load_profile_json("r04_pmc_m1.json") if m1.d.world == 1 else None
+    for key, base in (("ntt_forward", "ntt14::fwd_kernel"), ("mul_intt_fused", "ntt14::inv_kernel")):
+        krec = (rec or {}).get("kernels", {}).get(base)
+        if krec and krec.get("hbm_bytes_per_launch"):  # counted HBM bytes per launch (committed rocprofv3 --pmc passes of `--workload m1`)
+            out[key]["traffic"] = krec["hbm_bytes_per_launch"]
+            out[key]["traffic_source"] = "profiles/r04_pmc_m1.json"
+            if krec.get("SQ_WAIT_ANY") and krec.get("SQ_WAVE_CYCLES"):
+                out[key]["SQ_WAIT_ANY_over_SQ_WAVE_CYCLES"] = round(krec["SQ_WAIT_ANY"] / krec["SQ_WAVE_CYCLES"], 3)
     mul_ms, inv_ms = m1.standalone_kernels()
     out["mod_mul"] = entry("elementwise_kernel<u32,mul,bcast> (pointwise mod-mul by a resident ring element, standalone)", mul_ms, m1.vec_bytes)
     out["ntt_inverse"] = entry("ntt14::inv_kernel<u32,signed> (inverse negacyclic NTT, standalone)", inv_ms, m1.vec_bytes)
     out["step_ms"] = res["ms_per_step"]
     out["ring_mults_per_s"] = res["value"]
     return out
+
+
+def exchange_report(mx, wls, ranks_seen, backend, devices):
+    """What the multi-GPU exchange of this line actually was: how many ranks the communicator holds, which backend moved
+    the blocks, whether the devices can address each other, and that every rank validated every foreign block."""
+    from mxx_amd import _ffi
+
+    checked = [getattr(w, "foreign_blocks_checked", None) for w in wls]
+    try:
+        peer = _ffi.peer_access_matrix(sorted(set(devices)))
+    except Exception as e:  # noqa: BLE001 - a report, not a gate
+        peer = f"unavailable: {e}"
+    return {"ranks_seen": ranks_seen, "comm_backend": backend, "devices": devices, "peer_access": peer,
+            "foreign_blocks_checked_per_rank": checked,
+            "self_validated": all(c is not None for c in checked),
+            "distinct_devices": len(set(devices)) == len(devices)}
+
+
+def torch_exchange_report(wl, d):
+    """one process per GPU: every rank reports its device and how many foreign blocks it validated (collective)"""
+    from mxx_amd import _ffi
+
+    mine = {"rank": d.rank, "device": wl.device, "foreign_blocks_checked": getattr(wl, "foreign_blocks_checked", None)}
+    everyone = d.gather_objects(mine)
+    devices = [e["device"] for e in everyone]
+    try:
+        peer = _ffi.peer_access_matrix(sorted(set(devices)))
+    except Exception as e:  # noqa: BLE001
+        peer = f"unavailable: {e}"
+    checked = [e["foreign_blocks_checked"] for e in everyone]
+    return {"ranks_seen": d.dist.get_world_size(), "comm_backend": f"torch.distributed '{d.backend}'" + (" (RCCL)" if d.backend == "nccl" else " (rehearsal, not xGMI)"),
+            "devices": devices, "peer_access": peer, "foreign_blocks_checked_per_rank": checked,
+            "self_validated": all(c is not None for c in checked),
+            "distinct_devices": len(set(devices)) == len(devices)}
 
 
 def run_block_inproc(mx, wls, comm, steps, warmup, repeats):
@@ -750,9 +1016,14 @@ def run_block_inproc(mx, wls, comm, steps, warmup, repeats):
 
     n = len(wls)
     fulls = {}
+    # what each worker hands to the exchange of step i: published BEFORE the step's barrier, in the slot i & 1, so the
+    # gathering thread never reads a workload's live attributes while its worker is already inside step i + 1 (ADVICE r3:
+    # MatMul re-points self.out, Preimage replaces self.x).  Slot i & 1 is written again only in step i + 2, which no
+    # worker can reach before rank 0 has passed the barrier of step i + 1, i.e. has finished enqueueing the gather of step i.
+    published = [[None] * n, [None] * n]
 
-    def gather(slot):
-        fulls[slot] = comm.all_gather_columns([wl.local_block() for wl in wls], fulls.get(slot))
+    def gather(slot, blocks):
+        fulls[slot] = comm.all_gather_columns(list(blocks), fulls.get(slot))
         for wl, f in zip(wls, fulls[slot]):
             wl.full = f
 
@@ -766,9 +1037,10 @@ def run_block_inproc(mx, wls, comm, steps, warmup, repeats):
                 for i in range(k):
                     wls[r].step(i, mark)
                     if per_step:
+                        published[i & 1][r] = wls[r].local_block()
                         step_barrier.wait()
                         if r == 0:
-                            gather(i & 1)
+                            gather(i & 1, published[i & 1])
             except BaseException as e:  # noqa: BLE001 - reported by the main thread
                 errors.append(e)
                 step_barrier.abort()
@@ -784,7 +1056,7 @@ def run_block_inproc(mx, wls, comm, steps, warmup, repeats):
         if errors:
             raise errors[0]
         if comm is not None and not per_step and k:
-            gather(0)  # the region's one exchange step
+            gather(0, [wl.local_block() for wl in wls])  # the region's one exchange step: every worker has joined
         mx.gpu_device_sync()
         return time.perf_counter() - t0
 
@@ -838,6 +1110,8 @@ def main_inproc(args, emit):
         line = block_json(wls[0], res, ranks[0], args, args.steps, args.warmup)
         line["config"]["comm_backend"] = comm.backend if comm is not None else None
         line["config"]["devices"] = [r % ndev for r in range(n)]
+        line["exchange"] = exchange_report(mx, wls, len(comm) if comm is not None else n, comm.backend if comm is not None else None,
+                                           [r % ndev for r in range(n)])
         if comm is not None:
             comm.close()
         return line
@@ -915,18 +1189,30 @@ def main():
         return {"scaling": "weak", "value": r["value"], "ms_per_step": r["ms_per_step"], "units_per_step": w.units,
                 "sharding": w.sharding}
 
+    def sub_block(name, steps_, repeats_, composed=True, cpu=True):
+        """One more BASELINE configuration inside the default line: its own value / ms_per_step / repeats / roofline
+        (composed from the launch trace for multi-kernel calls) and CPU baseline; keys shared with the top level dropped."""
+        w, r = run(name, steps_, warmup, repeats_)
+        blk = block_json(w, r, d, args, steps_, warmup)
+        for key in ("n_gpus", "higher_is_better", "vs_baseline", "data"):
+            blk.pop(key, None)
+        blk["call_ms_hipevents"] = round(r["kernel_ms"][0], 4)
+        if composed and d.world == 1 and not args.no_trace:
+            blk["roofline"] = composed_roofline(w, r["kernel_ms"][0])
+        if cpu and d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:
+            blk["cpu_baseline"] = cpu_baseline(name, args.cpu_seconds / 2)
+        return w, r, blk
+
     if args.workload == "default":
         wl, res = run("m2a", steps, warmup, args.repeats)
         line = block_json(wl, res, d, args, steps, warmup)
+        line["output_buffers"] = ("the product writes into pre-allocated output matrices; the reference's timed `&left * &right` "
+                                  "also creates its output (src/matrix/gpu_dcrt_poly.rs:1792-1815) - microseconds from the stream-ordered cache")
         del wl
         if d.world > 1 and args.scaling == "strong":
             line["independent_units"] = independent_units("m2a")
-        pre_wl, pre_res = run("m3a", steps, warmup, min(args.repeats, 3))
-        pre = block_json(pre_wl, pre_res, d, args, steps, warmup)
-        for key in ("n_gpus", "higher_is_better", "vs_baseline", "data", "scaling"):
-            pre.pop(key, None)
-        pre.pop("roofline", None)
-        pre["call_ms_hipevents"] = round(pre_res["kernel_ms"][0], 4)
+        pre_wl, pre_res, pre = sub_block("m3a", steps, min(args.repeats, 3), cpu=False)
+        pre.pop("scaling", None)
         if d.world > 1 and args.scaling == "strong":
             del pre_wl
             pre["independent_units"] = independent_units("m3a")
@@ -953,6 +1239,31 @@ def main():
         del m1
         if d.world == 1:
             line["kernels"]["large_batch"] = large_batch_kernels(mx, device)
+        # ---- the remaining BASELINE configurations: M2B product + decompose + mul_decompose, M3B, M4 ----
+        m2b_wl, m2b_res, m2b = sub_block("m2b", steps, min(args.repeats, 3), composed=False, cpu=True)
+        m2b["roofline"]["also"] = ("dense contraction, 5.3 MAC/B: bound by L2 -> LDS operand delivery, not HBM (DESIGN.md section 5); "
+                                   "integer-MAC floor at 5.0 cycles per v_mad_u64_u32: "
+                                   f"{64 ** 3 * N_RING * 8 * 5.0 / 64 / (SIMDS * CLOCK_GHZ * 1e9) * 1e3:.2f} ms")
+        del m2b_wl
+        if d.world == 1:
+            _, _, dec = sub_block("m2b_decompose", max(2, steps // 4), 2, cpu=False)
+            m2b["decompose"] = dec
+            _, _, md = sub_block("m2b_mul_decompose", max(2, steps // 4), 2, cpu=False)
+            m2b["mul_decompose"] = md
+        line["m2b"] = m2b
+        w3, r3, m3b = sub_block("m3b", steps, min(args.repeats, 3))
+        del w3
+        line["preimage_m3b"] = m3b
+        w4, r4, m4 = sub_block("m4", steps, min(args.repeats, 3))
+        del w4
+        line["chain_m4"] = m4
+        line["baseline_configs"] = {
+            "configs[0] (plumbing, n=2^12, L=2, 4x4)": "CPU-runnable parity case: tests/test_gpu_surface.py + tests/test_oracle.py, not a bench line",
+            "configs[1] (NTT / INTT / mod-mul, n=2^14, L=4, 1024 polys)": "kernels",
+            "configs[2] (64x64 product + gadget decompose, n=2^14, L=8)": "m2b (product), m2b.decompose, m2b.mul_decompose",
+            "configs[3] (bench_preimage shape, L=8)": "preimage_m3b (the reference bench's own L=10 shape: preimage)",
+            "configs[4] (GGH15 mod-p chain parameters, n=256, 51-bit limbs)": "chain_m4",
+            "benches/bench_matrix_mul_gpu.rs shape (the metric's own)": "top level (M2A)"}
         if d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:  # an N = 1 leg: the other ranks would wait for it
             line["cpu_baseline"] = cpu_baseline("m2a", args.cpu_seconds)
             line["preimage"]["cpu_baseline"] = cpu_baseline("m3a", args.cpu_seconds)
@@ -964,9 +1275,13 @@ def main():
             line["kernels"] = kernels_block(wl, res)
             if d.world == 1:
                 del wl
+                wl = None
                 line["kernels"]["large_batch"] = large_batch_kernels(mx, device)
+        elif d.world == 1 and not args.no_trace and not isinstance(wl, MatMul):
+            line["roofline"] = composed_roofline(wl, res["kernel_ms"][0])
         if d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:  # an N = 1 leg: the other ranks would wait for it
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+            base_name = {"m2b_decompose": None, "m2b_mul_decompose": None}.get(args.workload, args.workload)
+            line["cpu_baseline"] = cpu_baseline(base_name, args.cpu_seconds) if base_name else None
     if d.rank == 0:
         line.setdefault("cpu_baseline", None)
         emit(line)

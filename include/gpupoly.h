@@ -257,11 +257,27 @@ const char *gpupoly_comm_backend(const GpuComm *comm); /* "rccl" or "peer" */
  * every s; full[s] takes the blocks' format tag.  Shards may be uneven or empty.  Enqueued on the contexts' streams
  * behind whatever produced the blocks; the host does not block; a block may be overwritten or destroyed right after
  * the call.  One row and equal shards gather straight into full[s]; other shapes go through a padded staging block
- * of the context's allocator.  Call it from one host thread (after the per-device workers have joined).           */
+ * of the context's allocator.  One collective at a time per communicator (calls serialise on its mutex); other host
+ * threads may keep enqueueing work on the contexts' streams meanwhile, as long as nothing enqueued after the call
+ * writes a block that was passed to it before the call returns.  The outputs' format tags change only on success. */
 int gpupoly_matrix_all_gather_columns(GpuComm *comm, const GpuMatrix *const *local_blocks, GpuMatrix *const *full);
 /* kernel launches issued by the library since it was loaded (every context; copies / memsets not counted): bench.py
  * reports launches per step for the launch-bound small-ring chain                                              */
 uint64_t gpupoly_launch_count(void);
+/* Launch trace (bench.py's composed roofline of a multi-kernel call: a preimage, a chain step).  Between _begin and
+ * _end every kernel launch and every device-to-device copy of the library - any context, any host thread - is
+ * bracketed by two hipEvents on the stream it is enqueued on.  _end stops recording, waits for the recorded work and
+ * returns one line per launch in launch order: "kernel \t blocks \t threads \t algorithmic bytes \t ms \n" (bytes = the
+ * launch's operands read once + written once, 0 where the launcher does not state them).  The string belongs to the
+ * library and stays valid until the next _begin / _end; NULL on error.  Tracing costs two event records per launch:
+ * durations are the kernels' own, the call's wall time is not what an untraced call takes.                       */
+/* 1 if `device` can address `peer`'s memory directly (xGMI peer mapping; a device always reaches itself) */
+int gpupoly_device_can_access_peer(int device, int peer, int *out_can);
+/* a one-thread no-op kernel (`gpupoly_marker_kernel`) on the context's stream: delimits bench.py's timed region in a
+ * profiler's dispatch list (tools/pmc_window.py counts only what lies between two markers)                     */
+int gpupoly_marker_launch(GpuContext *ctx, uint32_t id);
+int gpupoly_trace_begin(void);
+const char *gpupoly_trace_end(void);
 const char *gpupoly_version(void);
 /* MXX_HIP_* switches are read once, at gpu_context_create; this re-reads them for every live
  * context of the process (tests flip them between calls).                      */

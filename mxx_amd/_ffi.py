@@ -134,6 +134,10 @@ SIGNATURES = {
     "gpupoly_comm_backend": (C.c_char_p, [_vp]),
     "gpupoly_matrix_all_gather_columns": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "gpupoly_launch_count": (C.c_uint64, []),
+    "gpupoly_device_can_access_peer": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "gpupoly_marker_launch": (C.c_int, [_vp, C.c_uint32]),
+    "gpupoly_trace_begin": (C.c_int, []),
+    "gpupoly_trace_end": (C.c_char_p, []),
     "gpupoly_version": (C.c_char_p, []),
     "gpupoly_reload_env": (C.c_int, []),
 }
@@ -174,6 +178,23 @@ def reload_env() -> None:
     check_status(lib().gpupoly_reload_env(), "gpupoly_reload_env")
 
 
+def trace_begin() -> None:
+    """Start the library's launch trace (every kernel / device copy bracketed by hipEvents on its own stream)."""
+    check_status(lib().gpupoly_trace_begin(), "gpupoly_trace_begin")
+
+
+def trace_end() -> list[dict]:
+    """Stop the trace; one dict per launch in launch order: kernel, blocks, threads, bytes (0 = not stated), ms."""
+    text = lib().gpupoly_trace_end()
+    if text is None:
+        raise GpuPolyError(f"gpupoly_trace_end failed: {last_error_string()}")
+    out = []
+    for ln in text.decode().splitlines():
+        name, blocks, threads, nbytes, ms = ln.split("\t")
+        out.append({"kernel": name.strip("()"), "blocks": int(blocks), "threads": int(threads), "bytes": float(nbytes), "ms": float(ms)})
+    return out
+
+
 def gpu_device_sync() -> None:
     check_status(lib().gpu_device_synchronize(), "gpu_device_synchronize")
 
@@ -183,6 +204,20 @@ def detected_gpu_device_ids() -> list[int]:
     if lib().gpu_device_count(C.byref(n)) != 0 or n.value <= 0:
         return []
     return list(range(n.value))
+
+
+def peer_access_matrix(devices=None) -> list[list[int]]:
+    """[i][j] = 1 when device i can address device j's memory directly (xGMI peer mapping)."""
+    devs = detected_gpu_device_ids() if devices is None else list(devices)
+    out = []
+    for a in devs:
+        row = []
+        for b in devs:
+            can = C.c_int(0)
+            check_status(lib().gpupoly_device_can_access_peer(a, b, C.byref(can)), "gpupoly_device_can_access_peer")
+            row.append(int(can.value))
+        out.append(row)
+    return out
 
 
 def detected_gpu_device_count() -> int:

@@ -580,6 +580,8 @@ static int launch_elementwise_typed(GpuMatrix *out, const GpuMatrix *a, const Gp
     const size_t wpp = matrix_limbs(out) * static_cast<size_t>(ctx->N);
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
     constexpr int VNATIVE = 16 / sizeof(W);
+    // out written once; a and b read once each (a broadcast operand is one resident ring element; OP_NEG reads one operand)
+    MXX_TRACE_BYTES(static_cast<double>(words) * sizeof(W) * (1 + (OP == OP_NEG || BCAST || a == b ? 1 : 2)));
     if (ctx->N >= VNATIVE) {
         const size_t vecs = words / VNATIVE;
         unsigned blocks = static_cast<unsigned>(std::min<size_t>((vecs + 255) / 256, 16384));
@@ -677,7 +679,8 @@ extern "C" int gpupoly_matrix_ntt_add_rows(GpuMatrix *out, size_t dst_row, GpuMa
         coeff->format = GPU_POLY_FORMAT_EVAL;
         return launch_elementwise<OP_ADD, false>(&view, coeff, addend);
     }
-    HIP_TRY(hipMemcpyAsync(view.data, coeff->data, view.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    MXX_TRACED_COPY("copy (device to device)", ctx->stream, 2.0 * view.bytes,
+                    HIP_TRY(hipMemcpyAsync(view.data, coeff->data, view.bytes, hipMemcpyDeviceToDevice, ctx->stream)));
     int rc = launch_ntt(ctx, view.data, polys * L, static_cast<int>(L), false);
     if (rc) return rc;
     return launch_elementwise<OP_ADD, false>(&view, &view, addend);  // in place: every word is read, then written
@@ -796,6 +799,7 @@ extern "C" int gpu_matrix_mul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMat
         HIP_TRY(hipMemsetAsync(out->data, 0, out->bytes, out->ctx->stream));
         return 0;
     }
+    MXX_TRACE_BYTES(static_cast<double>(lhs->bytes) + rhs->bytes + out->bytes);  // (r m + m c + r c) n L w
     return launch_matmul(out, lhs, rhs);
     ABI_GUARD_END
 }

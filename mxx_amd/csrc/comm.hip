@@ -209,13 +209,17 @@ extern "C" void gpupoly_comm_destroy(GpuComm *comm) {
         RcclApi *api = rccl_api();
         for (size_t i = 0; i < comm->comms.size(); ++i) {
             if (!comm->comms[i]) continue;
-            (void)hipSetDevice(comm->ctxs[i]->device);
-            (void)hipStreamSynchronize(comm->ctxs[i]->stream);  // a communicator must not go away under its own collective
+            // a communicator must not go away under its own collective - but its contexts may be gone already (a host
+            // wrapper finalised at interpreter shutdown): the raw pointers are only followed while still registered
+            if (ctx_is_registered(comm->ctxs[i])) {
+                (void)hipSetDevice(comm->ctxs[i]->device);
+                (void)hipStreamSynchronize(comm->ctxs[i]->stream);
+            }
             (void)api->CommDestroy(comm->comms[i]);
         }
     }
     for (size_t i = 0; i < comm->ready.size(); ++i) {
-        (void)hipSetDevice(comm->ctxs[i]->device);
+        if (ctx_is_registered(comm->ctxs[i])) (void)hipSetDevice(comm->ctxs[i]->device);
         if (comm->ready[i]) (void)hipEventDestroy(comm->ready[i]);
         if (comm->done[i]) (void)hipEventDestroy(comm->done[i]);
     }
@@ -257,11 +261,16 @@ extern "C" int gpupoly_matrix_all_gather_columns(GpuComm *comm, const GpuMatrix 
         if (full[r]->cols != cols_total)
             return set_error("gpupoly_matrix_all_gather_columns: output must have the sum of the blocks' columns");
     const int fmt = local_blocks[0]->format;
-    for (size_t r = 0; r < n; ++r) full[r]->format = fmt;  // RCCL moves bytes: the tag travels here
     const size_t rows = local_blocks[0]->rows;
-    if (rows == 0 || cols_total == 0) return 0;
     const size_t poly_bytes = matrix_limbs(local_blocks[0]) * static_cast<size_t>(comm->ctxs[0]->N) * comm->ctxs[0]->word_bytes;
     std::lock_guard<std::mutex> lk(comm->mutex);
+    // RCCL moves bytes: the tag travels here - once everything is enqueued, so an error return leaves the outputs' tags
+    // alone, and under the communicator's mutex
+    auto retag = [&]() {
+        for (size_t r = 0; r < n; ++r) full[r]->format = fmt;
+        return 0;
+    };
+    if (rows == 0 || cols_total == 0) return retag();
 
     if (!comm->use_rccl) {
         // pull: context r copies every block into its own full matrix on its own stream, after the event that marks the
@@ -291,7 +300,7 @@ extern "C" int gpupoly_matrix_all_gather_columns(GpuComm *comm, const GpuMatrix 
             for (size_t r = 0; r < n; ++r)
                 if (r != p) HIP_TRY(hipStreamWaitEvent(comm->ctxs[p]->stream, comm->done[r], 0));
         }
-        return 0;
+        return retag();
     }
 
     RcclApi *api = rccl_api();
@@ -344,6 +353,6 @@ extern "C" int gpupoly_matrix_all_gather_columns(GpuComm *comm, const GpuMatrix 
             }
         }
     }
-    return 0;  // the staging blocks return to their contexts' caches here, stream-ordered behind their readers
+    return retag();  // the staging blocks return to their contexts' caches here, stream-ordered behind their readers
     ABI_GUARD_END
 }

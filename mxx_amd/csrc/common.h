@@ -146,10 +146,36 @@ __device__ __forceinline__ size_t item_index() {
 // every kernel launch of the library goes through this (bench.py prints launches per step for the launch-bound
 // small-ring chain: gpupoly_launch_count)
 extern std::atomic<uint64_t> g_kernel_launches;
-#define MXX_LAUNCH(...)                                             \
-    do {                                                            \
-        g_kernel_launches.fetch_add(1, std::memory_order_relaxed);  \
-        hipLaunchKernelGGL(__VA_ARGS__);                            \
+// Launch trace (gpupoly_trace_begin / gpupoly_trace_end, runtime.hip): while it is on, every launch is bracketed by two
+// hipEvents on the stream it is launched on and recorded with its kernel's name, grid and - where the launcher states
+// them with MXX_TRACE_BYTES - the algorithmic bytes of its operands (each read once + written once).  bench.py composes
+// the roofline of a multi-kernel call (a preimage, a chain step) from it.  Off: one relaxed load per launch.
+extern std::atomic<int> g_trace_on;
+void trace_launch_begin(const char *name, hipStream_t stream, dim3 grid, dim3 block);
+void trace_launch_end(hipStream_t stream);
+void trace_set_bytes(double bytes);
+#define MXX_TRACE_BYTES(b)                                                                        \
+    do {                                                                                          \
+        if (g_trace_on.load(std::memory_order_relaxed)) trace_set_bytes(static_cast<double>(b)); \
+    } while (0)
+#define MXX_LAUNCH(kern, grid, block, lds, strm, ...)                          \
+    do {                                                                       \
+        g_kernel_launches.fetch_add(1, std::memory_order_relaxed);             \
+        const bool mxx_tr_ = g_trace_on.load(std::memory_order_relaxed) != 0;  \
+        if (mxx_tr_) trace_launch_begin(#kern, strm, grid, block);             \
+        hipLaunchKernelGGL(kern, grid, block, lds, strm, __VA_ARGS__);         \
+        if (mxx_tr_) trace_launch_end(strm);                                   \
+    } while (0)
+// a runtime copy / memset on the context's stream, traced like a launch (the statement is the HIP_TRY'd call)
+#define MXX_TRACED_COPY(name, strm, bytes, stmt)                               \
+    do {                                                                       \
+        const bool mxx_tr_ = g_trace_on.load(std::memory_order_relaxed) != 0;  \
+        if (mxx_tr_) {                                                         \
+            trace_set_bytes(static_cast<double>(bytes));                       \
+            trace_launch_begin(name, strm, dim3(0), dim3(0));                  \
+        }                                                                      \
+        stmt;                                                                  \
+        if (mxx_tr_) trace_launch_end(strm);                                   \
     } while (0)
 
 // ---- error plumbing ---------------------------------------------------------
@@ -196,6 +222,7 @@ inline size_t matrix_words(const GpuMatrix *m) { return matrix_polys(m) * matrix
 int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t full_ncol, size_t col_offset, bool keep_coeff);
 
 int ctx_activate(const GpuContext *ctx);                   // hipSetDevice
+bool ctx_is_registered(const GpuContext *ctx);             // still a live context of this process (runtime.hip's registry)
 int ctx_alloc(GpuContext *ctx, size_t bytes, void **out);  // stream-ordered
 void ctx_free(GpuContext *ctx, void *ptr);                 // stream-ordered
 // a stream-ordered block that goes back to the context's cache when the scope ends (error paths

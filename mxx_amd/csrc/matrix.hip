@@ -118,6 +118,7 @@ int launch_scatter_i64(GpuMatrix *out, const int64_t *vals) {
     size_t total = polys * ctx->N;
     const dim3 blocks = item_grid(total, 256);
     uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
+    MXX_TRACE_BYTES(static_cast<double>(total) * 8 + out->bytes);  // int64 staging read, residues of every limb written
     if (ctx->wide)
         MXX_LAUNCH(scatter_i64_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<uint64_t *>(out->data), vals, ctx->d_limbs, polys, L, (uint32_t)ctx->N);
@@ -155,17 +156,21 @@ int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size
             CtxBlock tmp(ctx);  // back to the cache at scope exit, error paths included
             size_t row_bytes = cols * wpp * wb;
             if (tmp.alloc(rows * row_bytes)) return 1;
-            HIP_TRY(hipMemcpy2DAsync(tmp.ptr, row_bytes, s, src->cols * wpp * wb, row_bytes, rows,
-                                     hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, tmp.ptr, row_bytes, row_bytes, rows,
-                                     hipMemcpyDeviceToDevice, ctx->stream));
+            MXX_TRACED_COPY("copy_block (2-D runtime copy)", ctx->stream, 2.0 * rows * row_bytes,
+                            HIP_TRY(hipMemcpy2DAsync(tmp.ptr, row_bytes, s, src->cols * wpp * wb, row_bytes, rows,
+                                                     hipMemcpyDeviceToDevice, ctx->stream)));
+            MXX_TRACED_COPY("copy_block (2-D runtime copy)", ctx->stream, 2.0 * rows * row_bytes,
+                            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, tmp.ptr, row_bytes, row_bytes, rows,
+                                                     hipMemcpyDeviceToDevice, ctx->stream)));
             return 0;
         }
         if (rows == 1 || (cols == src->cols && cols == out->cols)) {
-            HIP_TRY(hipMemcpyAsync(d, s, rows * cols * wpp * wb, hipMemcpyDeviceToDevice, ctx->stream));
+            MXX_TRACED_COPY("copy_block (runtime copy)", ctx->stream, 2.0 * rows * cols * wpp * wb,
+                            HIP_TRY(hipMemcpyAsync(d, s, rows * cols * wpp * wb, hipMemcpyDeviceToDevice, ctx->stream)));
         } else {
-            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, s, src->cols * wpp * wb, cols * wpp * wb, rows,
-                                     hipMemcpyDeviceToDevice, ctx->stream));
+            MXX_TRACED_COPY("copy_block (2-D runtime copy)", ctx->stream, 2.0 * rows * cols * wpp * wb,
+                            HIP_TRY(hipMemcpy2DAsync(d, out->cols * wpp * wb, s, src->cols * wpp * wb, cols * wpp * wb, rows,
+                                                     hipMemcpyDeviceToDevice, ctx->stream)));
         }
         return 0;
     }
@@ -178,6 +183,7 @@ int launch_copy_block(GpuMatrix *out, const GpuMatrix *src, size_t dst_row, size
     for (size_t r0 = 0; r0 < rows; r0 += rows_per_launch) {
         size_t rr = std::min(rows_per_launch, rows - r0);
         dim3 grid(gx, static_cast<unsigned>(rr * cols));
+        MXX_TRACE_BYTES(3.0 * rr * cols * wpp * ctx->word_bytes);  // destination block read + written, source block read
         if (ctx->wide)
             MXX_LAUNCH((block_rect_kernel<uint64_t, true>), grid, dim3(256), 0, ctx->stream,
                                static_cast<uint64_t *>(out->data), static_cast<const uint64_t *>(src->data),
@@ -254,7 +260,8 @@ extern "C" int gpu_matrix_copy(GpuMatrix *dst, const GpuMatrix *src) {
     dst->format = src->format;
     if (dst->bytes == 0 || dst == src) return 0;
     if (ctx_activate(dst->ctx)) return 1;
-    HIP_TRY(hipMemcpyAsync(dst->data, src->data, dst->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
+    MXX_TRACED_COPY("copy (device to device)", dst->ctx->stream, 2.0 * dst->bytes,
+                    HIP_TRY(hipMemcpyAsync(dst->data, src->data, dst->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream)));
     return 0;
     ABI_GUARD_END
 }

@@ -127,7 +127,7 @@ static int launch_generic(GpuContext *ctx, W *data, size_t vectors, uint32_t L) 
     unsigned threads = static_cast<unsigned>(N / 2);
     if (threads < 64) threads = 64;
     if (threads > 512) threads = 512;
-    MXX_LAUNCH(kern, dim3(static_cast<unsigned>(vectors)), dim3(threads), lds, ctx->stream, data,
+    MXX_LAUNCH((ntt_generic_kernel<W, INV>), dim3(static_cast<unsigned>(vectors)), dim3(threads), lds, ctx->stream, data,
                        static_cast<const W *>(INV ? ctx->d_tw_inv : ctx->d_tw_fwd),
                        static_cast<const W *>(INV ? ctx->d_tw_inv_sh : ctx->d_tw_fwd_sh), ctx->d_limbs, L, logN);
     HIP_TRY(hipGetLastError());
@@ -183,6 +183,7 @@ int launch_ntt(GpuContext *ctx, void *data, size_t vectors, int limbs_per_poly, 
     if (vectors == 0) return 0;
     if (vectors > 0x7fffffffull) return set_error("ntt: too many vectors for one launch");
     const uint32_t L = static_cast<uint32_t>(limbs_per_poly);
+    MXX_TRACE_BYTES(2.0 * vectors * ctx->N * ctx->word_bytes);  // read once + write once (all launches of a split transform)
     if (ctx->wide) {
         return inverse ? launch_ntt_typed<uint64_t, true>(ctx, static_cast<uint64_t *>(data), vectors, L)
                        : launch_ntt_typed<uint64_t, false>(ctx, static_cast<uint64_t *>(data), vectors, L);

@@ -25,10 +25,10 @@ int launch_ntt_add_u32(GpuContext *ctx, uint32_t *out, const uint32_t *src, cons
     if (vectors > 0x7fffffffull || !ntt14_grid(vectors, L, grid)) return -1;
     const size_t lds = ntt14::lds_bytes(sizeof(W));
     const TwPair<W> *tw = static_cast<const TwPair<W> *>(ctx->d_tw2_fwd);
+    MXX_TRACE_BYTES(3.0 * vectors * ntt14::N * sizeof(W));  // coefficients + addend read, the sum's transform written
     if (ctx->lazy_ok) MXX_LAUNCH((ntt14::fwd_add_kernel<W, false>), grid, block, lds, ctx->stream, out, src, add, tw, ctx->d_limbs, L);
     else MXX_LAUNCH((ntt14::fwd_add_kernel<W, true>), grid, block, lds, ctx->stream, out, src, add, tw, ctx->d_limbs, L);
     HIP_TRY(hipGetLastError());
-    ctx->last_kernel = "ntt14::fwd_add_kernel";
     return 0;
 }
 
@@ -50,6 +50,8 @@ int launch_ntt_digits_u32(GpuContext *ctx, uint32_t *out, const uint32_t *coeff,
     for (uint32_t l = 0; l < L; ++l) min_q = std::min<uint64_t>(min_q, ctx->moduli[l]);
     const bool reduce = digit_bits >= 63 || ((1ull << digit_bits) - 1) >= min_q;
     (void)towers;
+    // SURVEY 8d decompose: (r c + r k c) n L w - the source read once, the digit matrix written once
+    MXX_TRACE_BYTES((static_cast<double>(src_rows) * src_cols * L + static_cast<double>(out_vectors)) * ctx->N * sizeof(W));
     if (ctx->logN != 14) return dispatch_ntt_digits(ctx, out, coeff, L, src_cols, src_rows, dpt, base_bits, k, reduce);
     const dim3 grid(8u * L * ((src_cols + 7u) / 8u), static_cast<unsigned>(k), static_cast<unsigned>(src_rows));
     const dim3 block(ntt14::T);

@@ -36,6 +36,127 @@ std::atomic<uint64_t> g_kernel_launches{0};
 extern "C" uint64_t gpupoly_launch_count(void) { return g_kernel_launches.load(std::memory_order_relaxed); }
 extern "C" const char *gpupoly_version(void) { return "gpupoly-mi355x 0.1 (gfx950)"; }
 
+// ---- launch trace (extension; common.h: MXX_LAUNCH) ----------------------------------------------------------
+std::atomic<int> g_trace_on{0};
+namespace {
+struct TraceEntry {
+    const char *name;
+    hipEvent_t e0, e1;
+    unsigned long long blocks;
+    unsigned threads;
+    double bytes;
+    int device;
+    bool closed;
+};
+std::mutex g_trace_mutex;
+std::vector<TraceEntry> g_trace;
+std::vector<hipEvent_t> g_trace_pool;  // events of earlier traces, reused
+std::string g_trace_report;
+thread_local double t_trace_bytes = 0;
+thread_local long t_trace_open = -1;
+hipEvent_t trace_event() {
+    if (!g_trace_pool.empty()) {
+        hipEvent_t e = g_trace_pool.back();
+        g_trace_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+void trace_set_bytes(double bytes) { t_trace_bytes = bytes; }
+
+void trace_launch_begin(const char *name, hipStream_t stream, dim3 grid, dim3 block) {
+    std::lock_guard<std::mutex> lk(g_trace_mutex);
+    TraceEntry en{name, trace_event(), trace_event(), 1ull * grid.x * grid.y * grid.z, block.x * block.y * block.z,
+                  t_trace_bytes, 0, false};
+    t_trace_bytes = 0;
+    t_trace_open = -1;
+    if (!en.e0 || !en.e1) return;
+    (void)hipGetDevice(&en.device);
+    if (hipEventRecord(en.e0, stream) != hipSuccess) return;
+    g_trace.push_back(en);
+    t_trace_open = static_cast<long>(g_trace.size()) - 1;
+}
+
+void trace_launch_end(hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_trace_mutex);
+    if (t_trace_open < 0 || static_cast<size_t>(t_trace_open) >= g_trace.size()) return;
+    TraceEntry &en = g_trace[static_cast<size_t>(t_trace_open)];
+    en.closed = hipEventRecord(en.e1, stream) == hipSuccess;
+    t_trace_open = -1;
+}
+
+// A one-thread kernel whose only purpose is its name in a profiler's dispatch list: bench.py launches one on each side of
+// its timed region, and tools/pmc_window.py sums rocprofv3's per-dispatch counters BETWEEN the two - the set-up's launches
+// of the same kernels (other sizes) stay out of the per-launch figures.
+__global__ void gpupoly_marker_kernel(uint32_t id, uint32_t *sink) {
+    if (sink && id == 0xffffffffu) *sink = id;  // never true for the ids bench.py uses: the kernel has no effect
+}
+extern "C" int gpupoly_marker_launch(GpuContext *ctx, uint32_t id) {
+    ABI_GUARD_BEGIN
+    if (!ctx) return set_error("gpupoly_marker_launch: null ctx");
+    if (ctx_activate(ctx)) return 1;
+    hipLaunchKernelGGL(gpupoly_marker_kernel, dim3(1), dim3(1), 0, ctx->stream, id & 0x7fffffffu, static_cast<uint32_t *>(nullptr));
+    HIP_TRY(hipGetLastError());
+    return 0;
+    ABI_GUARD_END
+}
+
+// Start recording every launch of this library (all contexts, all threads).  Entries accumulate until gpupoly_trace_end.
+extern "C" int gpupoly_trace_begin(void) {
+    ABI_GUARD_BEGIN
+    std::lock_guard<std::mutex> lk(g_trace_mutex);
+    for (const TraceEntry &en : g_trace) {
+        g_trace_pool.push_back(en.e0);
+        g_trace_pool.push_back(en.e1);
+    }
+    g_trace.clear();
+    g_trace_on.store(1, std::memory_order_relaxed);
+    return 0;
+    ABI_GUARD_END
+}
+
+// Stop recording, wait for the recorded launches and return one line per launch, in launch order:
+// "name \t blocks \t threads per block \t algorithmic bytes (0: not stated) \t milliseconds \n".  The string belongs to the
+// library and stays valid until the next gpupoly_trace_begin / gpupoly_trace_end; NULL on error (gpu_last_error()).
+extern "C" const char *gpupoly_trace_end(void) {
+    try {
+        g_trace_on.store(0, std::memory_order_relaxed);
+        std::lock_guard<std::mutex> lk(g_trace_mutex);
+        g_trace_report.clear();
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        char line[512];
+        for (const TraceEntry &en : g_trace) {
+            if (!en.closed) continue;
+            (void)hipSetDevice(en.device);
+            float ms = 0;
+            hipError_t e = hipEventSynchronize(en.e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, en.e0, en.e1);
+            if (e != hipSuccess) {
+                (void)hipSetDevice(prev);
+                set_error(e, "gpupoly_trace_end: hipEventElapsedTime");
+                return nullptr;
+            }
+            std::snprintf(line, sizeof line, "%s\t%llu\t%u\t%.0f\t%.6f\n", en.name, en.blocks, en.threads, en.bytes, ms);
+            g_trace_report += line;
+        }
+        for (const TraceEntry &en : g_trace) {  // the events go back to the pool: a second _end reports nothing
+            g_trace_pool.push_back(en.e0);
+            g_trace_pool.push_back(en.e1);
+        }
+        g_trace.clear();
+        (void)hipSetDevice(prev);
+        return g_trace_report.c_str();
+    } catch (...) {
+        set_error("gpupoly_trace_end: exception");
+        return nullptr;
+    }
+}
+
 // ---- roctx (tracing) ---------------------------------------------------------------
 int (*g_roctx_push)(const char *) = nullptr;
 int (*g_roctx_pop)() = nullptr;
@@ -152,6 +273,10 @@ void EnvSwitches::load() {
 
 static std::mutex g_registry_mutex;
 static std::vector<GpuContext *> g_contexts;  // every live context of the process
+bool ctx_is_registered(const GpuContext *ctx) {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    return std::find(g_contexts.begin(), g_contexts.end(), ctx) != g_contexts.end();
+}
 
 extern "C" int gpupoly_reload_env(void) {
     std::lock_guard<std::mutex> lk(g_registry_mutex);
@@ -595,6 +720,21 @@ extern "C" int gpu_device_mem_info(int device, size_t *out_free, size_t *out_tot
     hipError_t e = hipMemGetInfo(out_free, out_total);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) return set_error(e, "hipMemGetInfo");
+    return 0;
+    ABI_GUARD_END
+}
+
+// can kernels / copies on `device` address `peer`'s memory directly (xGMI peer mapping)?  bench.py reports the matrix of a
+// multi-GPU run next to its numbers; a device can always reach itself
+extern "C" int gpupoly_device_can_access_peer(int device, int peer, int *out_can) {
+    ABI_GUARD_BEGIN
+    if (!out_can) return set_error("gpupoly_device_can_access_peer: null output");
+    *out_can = 0;
+    if (device == peer) {
+        *out_can = 1;
+        return 0;
+    }
+    HIP_TRY(hipDeviceCanAccessPeer(out_can, device, peer));
     return 0;
     ABI_GUARD_END
 }

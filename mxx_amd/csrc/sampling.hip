@@ -241,6 +241,7 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
+        MXX_TRACE_BYTES(static_cast<double>(total) * sizeof(int64_t));  // no input: the int64 samples written once
         MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
                            static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,
                            // one group per lane at most: the call lasts as long as its unluckiest lane's chain, which
@@ -268,6 +269,7 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
 #define MXX_SAMPLE(KERNEL, WORD, ...)                                                                                     \
     MXX_LAUNCH(KERNEL<WORD>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<WORD *>(out->data), ctx->d_limbs, \
                        d_keys, polys, out->cols, full_ncol, col_offset, L, N, groups, ##__VA_ARGS__)
+        MXX_TRACE_BYTES(static_cast<double>(out->bytes));  // no input: the residues written once
         if (uniform) {
             if (ctx->wide) MXX_SAMPLE(sample_uniform_kernel, uint64_t);
             else MXX_SAMPLE(sample_uniform_kernel, uint32_t);

@@ -411,6 +411,8 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
     const ChaChaKey key = chacha_subkey(seed, 0, kTagGadget);
     MXX_LAUNCH(gq_tower_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<GqTower *>(towers), ctx->d_limbs,
                        L, dpt, base_bits, c);
+    // per element: the residue read; dpt centres + the 8 - 2 dpt unused keystream words handed to pass 2
+    MXX_TRACE_BYTES(static_cast<double>(total) * (sizeof(W) + 8.0 * (8 - dpt)));
     MXX_LAUNCH((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
                        ctx->stream, a_words, left_words, src, ctx->d_limbs, key, total, L,
                        ctx->logN, dpt, base_bits, c);
@@ -418,11 +420,14 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
         sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device, ctx->env.sampler_per_lane);
     const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
+    MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * (8 - dpt) + 8.0 * dpt));  // pass 1's words read, dpt int64 digits written
     MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
                        static_cast<int64_t *>(stage), ctx->d_limbs, key,
                        static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
                        base_bits, c, karney_divisor(sigma), per_lane,
                        static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3));
+    // the int64 digits and the residue read; every digit written as a residue of every limb (the call's output: 655 MB at M3A)
+    MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * dpt + sizeof(W) + static_cast<double>(dpt) * L * sizeof(W)));
     MXX_LAUNCH(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
                        ctx->stream, out, static_cast<const int64_t *>(stage), src, ctx->d_limbs, total, src_cols, L, ctx->logN,
                        dpt, static_cast<uint32_t>(k), base_bits);
@@ -444,6 +449,7 @@ static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys
     if (!simple && dpt <= 4) return launch_gauss_samp_lanes<W, 4>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
     const dim3 blocks = item_grid(total, 128);
     const uint32_t N = static_cast<uint32_t>(ctx->N);
+    MXX_TRACE_BYTES(static_cast<double>(total) * (sizeof(W) + static_cast<double>(dpt) * L * sizeof(W)));
 #define LAUNCH_GS(MAXD)                                                                                        \
     MXX_LAUNCH((gauss_samp_gq_kernel<W, MAXD>), dim3(blocks), dim3(128), 0, ctx->stream, out, src,      \
                        ctx->d_limbs, polys, src_cols, L, N, dpt, base_bits, c, k, seed)
@@ -816,6 +822,10 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * m * sizeof(int64_t), &stage)) return 1;
         const ChaChaKey key = chacha_subkey(seed, 0, kTagP1);
+        // per (column, coefficient): m limb-0 residues of tp2, m standard deviations + divisors and m^2 update coefficients of
+        // the cache (the cache is per coefficient: re-read per column from L2 / the Infinity Cache), m int64 samples written
+        MXX_TRACE_BYTES(static_cast<double>(total) * m * (ctx->word_bytes + 8.0) +
+                        static_cast<double>(N) * m * (8.0 + sizeof(KarneyDivisor) + 8.0 * m));
 #define LAUNCH_P1L(WT, MAXM)                                                                                      \
     do {                                                                                                          \
         const uint32_t per_lane =                                                                                 \

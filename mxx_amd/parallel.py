@@ -38,6 +38,20 @@ def all_shard_ranges(total: int, world: int) -> list[ShardRange]:
     return [shard_range(total, world, r) for r in range(world)]
 
 
+def blocks_that_differ(cols_total: int, world: int, block_equal) -> list[int]:
+    """Self-validation of a column all-gather: the ranks whose block of the gathered matrix differs from the
+    expectation.  `block_equal(start, stop) -> bool` compares columns [start, stop) of the gathered matrix with a
+    recomputation (or, for randomised results, checks the predicate the columns must satisfy); empty shards are skipped.
+    bench.py runs it on EVERY rank over EVERY block, so a wrong peer offset, a missed wait or a stride bug in the
+    exchange fails the run instead of leaving garbage in the foreign 7/8 of the matrix (`src/sampler/trapdoor/gpu.rs:371-397`
+    is the fan-out whose results the exchange assembles)."""
+    bad = []
+    for r, sr in enumerate(all_shard_ranges(cols_total, world)):
+        if len(sr) and not block_equal(sr.start, sr.stop):
+            bad.append(r)
+    return bad
+
+
 def all_gather_column_blocks(local_block, cols_total: int, dist, device_tensor_of, world: int):
     """All-gather equally sized flattened column blocks.
 

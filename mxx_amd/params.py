@@ -156,6 +156,10 @@ class GpuContext:
         _ffi.check_status(_ffi.lib().gpupoly_context_word_bytes(self.raw, C.byref(d)), "gpupoly_context_word_bytes")
         return d.value
 
+    def marker(self, ident: int) -> None:
+        """A one-thread no-op kernel on the compute stream (delimits a timed region in a profiler's dispatch list)."""
+        _ffi.check_status(_ffi.lib().gpupoly_marker_launch(self.raw, ident), "gpupoly_marker_launch")
+
     def timer_start(self) -> None:
         _ffi.check_status(_ffi.lib().gpupoly_timer_start(self.raw), "gpupoly_timer_start")
 

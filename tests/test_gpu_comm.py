@@ -177,3 +177,85 @@ def test_sharded_product_and_preimage_gathered_in_process(gpu, oracle):
         assert f.ncol == 5 and a * f == gpu.GpuDCRTPolyMatrix.from_rns(p, t_rns, True)
     comm3.close()
     comm.close()
+
+
+def test_gathered_blocks_self_validation_and_shifted_offset(gpu, oracle):
+    """bench.py's self-validation on real gathered matrices (three contexts, uneven shards): every context checks EVERY
+    block against a recomputation; a gather whose columns are rotated by one - what a wrong peer offset produces - is
+    reported in every block, and a foreign block zeroed after the gather in exactly that block."""
+    from mxx_amd.parallel import GpuComm, all_shard_ranges, blocks_that_differ
+
+    ps = contexts_on_one_device(gpu, oracle, 3, n=256, depth=2)
+    comm = GpuComm(ps)
+    moduli, n = ps[0].moduli(), 256
+    a = oracle.matrix_ntt(rand_matrix(oracle, 61, 1, 4, moduli, n), moduli)
+    b = oracle.matrix_ntt(rand_matrix(oracle, 62, 4, 8, moduli, n), moduli)
+    ranges = all_shard_ranges(8, 3)
+    blocks = [gpu.GpuDCRTPolyMatrix.from_rns(p, a, True) * gpu.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(b[:, r.start:r.stop]), True)
+              for p, r in zip(ps, ranges)]
+    fulls = comm.all_gather_columns(blocks)
+    for p, f in zip(ps, fulls):
+        whole = gpu.GpuDCRTPolyMatrix.from_rns(p, a, True) * gpu.GpuDCRTPolyMatrix.from_rns(p, b, True)
+        eq = lambda m: (lambda lo, hi: m.slice_columns(lo, hi) == whole.slice_columns(lo, hi))
+        assert blocks_that_differ(8, 3, eq(f)) == []
+        shifted = f.slice_columns(1, 8).concat_columns([f.slice_columns(0, 1)])
+        assert blocks_that_differ(8, 3, eq(shifted)) == [0, 1, 2]
+        hole = f.clone()
+        hole.copy_block_from(gpu.GpuDCRTPolyMatrix.zero(p, 1, len(ranges[1])), 0, ranges[1].start, 0, 0, 1, len(ranges[1]))
+        assert blocks_that_differ(8, 3, eq(hole)) == [1]
+    comm.close()
+
+
+def test_bench_inproc_two_contexts_validates_foreign_blocks_and_fails_on_a_shift(gpu):
+    """`bench.py --gpus 2 --inproc` (two contexts sharing this box's device): the line reports the exchange - ranks seen,
+    backend, peer access, foreign blocks checked by every rank - and the same run with the gathered matrix rotated by one
+    column (MXX_BENCH_FAULT_INJECT=shift) exits non-zero."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MXX_BENCH_INPROC_SHARE_DEVICES="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--inproc", "--steps", "2", "--warmup", "1", "--repeats", "0",
+           "--no-trace"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for blk in (line, line["preimage"]):
+        ex = blk["exchange"]
+        assert ex["ranks_seen"] == 2 and ex["comm_backend"] == "peer" and ex["self_validated"] is True
+        assert ex["foreign_blocks_checked_per_rank"] == [1, 1] and ex["distinct_devices"] is False
+    bad = subprocess.run(cmd + ["--workload", "m2a"], env=dict(env, MXX_BENCH_FAULT_INJECT="shift"), capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and "differs from the recomputed one" in bad.stderr
+
+
+@pytest.mark.skipif("__import__('mxx_amd').detected_gpu_device_count() < 2")
+@pytest.mark.parametrize("backend", ["rccl", "peer"])
+@pytest.mark.parametrize("rows,shards", [(1, [2, 2]), (1, [3, 1]), (3, [2, 3]), (2, [0, 4]), (22, [4, 3])])
+def test_all_gather_columns_two_physical_devices(gpu, oracle, monkeypatch, backend, rows, shards):
+    """Runs only where two devices are visible (never on this pool's one-GPU boxes - ADVICE r3): the RCCL communicator
+    over distinct devices and the xGMI branches of the peer backend, even / uneven / empty / multi-row shards, against
+    the oracle's concatenation."""
+    from mxx_amd.parallel import GpuComm
+
+    monkeypatch.setenv("MXX_HIP_COMM", backend)
+    n, depth = 1024, 3
+    moduli = oracle.gen_crt_basis(n, depth, 24)
+    ps = [gpu.GpuDCRTPolyParams(n, moduli, 12, gpu_ids=[dev]) for dev in range(len(shards))]
+    comm = GpuComm(ps)
+    assert comm.backend == backend
+    total = sum(shards)
+    x = rand_matrix(oracle, 1200 + rows + total, rows, total, moduli, n)
+    want = oracle.matrix_ntt(x, moduli)
+    blocks, start = [], 0
+    for p, c in zip(ps, shards):
+        b = gpu.GpuDCRTPolyMatrix.from_rns(p, np.ascontiguousarray(x[:, start:start + c]), False)
+        b.ntt_all_in_place()
+        blocks.append(b)
+        start += c
+    fulls = comm.all_gather_columns(blocks)
+    del blocks
+    for p, f in zip(ps, fulls):
+        assert f.params is p and np.array_equal(f.to_rns(), want)
+    comm.close()

@@ -110,6 +110,70 @@ def test_place_column_blocks_unpads():
     assert np.array_equal(place_column_blocks(g, total), full)
 
 
+def test_blocks_that_differ_catches_a_shifted_offset():
+    """bench.py's self-validation of the exchange (every rank, every block): the exact gather passes, a gather whose
+    blocks land one column late (a wrong peer offset) or whose foreign block was never written fails - in the FOREIGN
+    blocks, which the round-3 check (own block only) could not see."""
+    from mxx_amd.parallel import blocks_that_differ
+
+    world, rows, total = 4, 3, 10
+    whole = np.arange(rows * total * 2).reshape(rows, total, 2)
+    eq = lambda m: (lambda lo, hi: np.array_equal(m[:, lo:hi], whole[:, lo:hi]))
+    assert blocks_that_differ(total, world, eq(whole.copy())) == []
+    shifted = np.roll(whole, 1, axis=1)
+    assert blocks_that_differ(total, world, eq(shifted)) == [0, 1, 2, 3]
+    stale = whole.copy()
+    sr = shard_range(total, world, 2)
+    stale[:, sr.start:sr.stop] = 0  # rank 2's block never arrived
+    assert blocks_that_differ(total, world, eq(stale)) == [2]
+    # an own-block-only check on rank 0 would have passed both: its block is exact in `stale`
+    s0 = shard_range(total, world, 0)
+    assert np.array_equal(stale[:, s0.start:s0.stop], whole[:, s0.start:s0.stop])
+    assert blocks_that_differ(7, 8, lambda lo, hi: True) == []  # an empty shard (7 columns on 8 ranks) is skipped
+
+
+def test_world_size_2_gloo_foreign_block_validation(tmp_path):
+    """two processes: each validates the WHOLE gathered product (its own block and the foreign one) against a
+    recomputation, as bench.py does; a gather with rank 1's block misplaced is caught on rank 0"""
+    script = tmp_path / "worker2.py"
+    script.write_text(textwrap.dedent(
+        """
+        import sys
+        sys.path.insert(0, {root!r})
+        import numpy as np, torch, torch.distributed as dist
+        from mxx_amd.parallel import shard_range, blocks_that_differ, place_column_blocks, padded_len
+        from oracle import oracle as O
+        dist.init_process_group(backend="gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        n, moduli = 16, O.gen_crt_basis(16, 2, 17)
+        A = O.matrix_ntt(O.random_matrix(1, 2, 3, moduli, n), moduli)
+        B = O.matrix_ntt(O.random_matrix(2, 3, 7, moduli, n), moduli)   # same seed on every rank: B is recomputable
+        sr, pad = shard_range(7, world, rank), padded_len(7, world)
+        block = np.zeros((2, pad, len(moduli), n), dtype=np.uint64)
+        block[:, :len(sr)] = O.matmul(A, np.ascontiguousarray(B[:, sr.start:sr.stop]), moduli)
+        recv = torch.empty(world * block.size, dtype=torch.int64)
+        dist.all_gather_into_tensor(recv, torch.from_numpy(block.reshape(-1).view(np.int64)))
+        g = recv.numpy().view(np.uint64).reshape((world,) + block.shape)
+        whole = O.matmul(A, B, moduli)
+        full = place_column_blocks(g, 7)
+        eq = lambda m: (lambda lo, hi: np.array_equal(m[:, lo:hi], whole[:, lo:hi]))
+        assert blocks_that_differ(7, world, eq(full)) == []
+        wrong = full.copy()
+        o = shard_range(7, world, 1)
+        wrong[:, o.start:o.stop] = np.roll(full[:, o.start:o.stop], 1, axis=1)   # rank 1's block lands shifted
+        assert blocks_that_differ(7, world, eq(wrong)) == [1]
+        ok = torch.tensor([1.0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if rank == 0: print("FOREIGN_OK", float(ok.item()))
+        dist.destroy_process_group()
+        """).format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "FOREIGN_OK 1.0" in out.stdout
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun and no RANK/WORLD_SIZE in the environment must spawn two ranks
     that reach init_process_group (gloo + --dry-run here: no GPU in this container) and all-reduce."""
