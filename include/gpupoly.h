@@ -271,6 +271,11 @@ uint64_t gpupoly_launch_count(void);
  * launch's operands read once + written once, 0 where the launcher does not state them).  The string belongs to the
  * library and stays valid until the next _begin / _end; NULL on error.  Tracing costs two event records per launch:
  * durations are the kernels' own, the call's wall time is not what an untraced call takes.                       */
+/* Test instrument: evaluates the samplers' deterministic math (mxx_amd/csrc/detmath.h) ON THE DEVICE for n host-supplied
+ * doubles - fn 0: log(x), 1: cos(2 pi x), 2: sqrt(-2 log x) - and copies the results back (synchronous).  The Box-Muller
+ * step of the G-lattice sampler (cuda/src/matrix/MatrixTrapdoor.cu:701-833 calls log / cos there) is the only place on the
+ * path with transcendental functions; this lets a test hold the device's results to libm within 2 ulp.           */
+int gpupoly_detmath_eval(GpuContext *ctx, int fn, const double *host_in, double *host_out, size_t n);
 /* 1 if `device` can address `peer`'s memory directly (xGMI peer mapping; a device always reaches itself) */
 int gpupoly_device_can_access_peer(int device, int peer, int *out_can);
 /* a one-thread no-op kernel (`gpupoly_marker_kernel`) on the context's stream: delimits bench.py's timed region in a

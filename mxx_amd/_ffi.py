@@ -134,6 +134,7 @@ SIGNATURES = {
     "gpupoly_comm_backend": (C.c_char_p, [_vp]),
     "gpupoly_matrix_all_gather_columns": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "gpupoly_launch_count": (C.c_uint64, []),
+    "gpupoly_detmath_eval": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _sz]),
     "gpupoly_device_can_access_peer": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "gpupoly_marker_launch": (C.c_int, [_vp, C.c_uint32]),
     "gpupoly_trace_begin": (C.c_int, []),

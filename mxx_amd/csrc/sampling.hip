@@ -285,6 +285,35 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
     return launch_ntt(ctx, out->data, polys * L, static_cast<int>(L), false);
 }
 
+// ---- detmath.h where it runs (extension, test instrument) ------------------------------------------------------
+// Box-Muller's log / cos(2 pi u) are fixed IEEE operation sequences compiled into the device code; this entry evaluates
+// them ON THE DEVICE for caller-supplied arguments so that a test can compare them with libm / extended precision
+// (tests/test_gpu_sampler_stats.py: 10^7 points, <= 2 ulp) - the CPU-side check alone compares the header with itself.
+__global__ void detmath_eval_kernel(double *__restrict__ out, const double *__restrict__ in, size_t n, int fn) {
+    const size_t i = item_index();
+    if (i >= n) return;
+    const double x = in[i];
+    out[i] = fn == 0 ? det_log(x) : (fn == 1 ? det_cos2pi(x) : sqrt(-2.0 * det_log(x)));
+}
+
+extern "C" int gpupoly_detmath_eval(GpuContext *ctx, int fn, const double *host_in, double *host_out, size_t n) {
+    ABI_GUARD_BEGIN
+    if (!ctx || !host_in || !host_out) return set_error("gpupoly_detmath_eval: null argument");
+    if (fn < 0 || fn > 2) return set_error("gpupoly_detmath_eval: fn must be 0 (log), 1 (cos 2 pi u) or 2 (sqrt(-2 log u))");
+    if (n == 0) return 0;
+    if (ctx_activate(ctx)) return 1;
+    CtxBlock din(ctx), dout(ctx);
+    if (din.alloc(n * sizeof(double)) || dout.alloc(n * sizeof(double))) return 1;
+    HIP_TRY(hipMemcpyAsync(din.ptr, host_in, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MXX_LAUNCH(detmath_eval_kernel, item_grid(n, 256), dim3(256), 0, ctx->stream, static_cast<double *>(dout.ptr),
+               static_cast<const double *>(din.ptr), n, fn);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_out, dout.ptr, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+    ABI_GUARD_END
+}
+
 extern "C" int gpu_matrix_sample_distribution(GpuMatrix *out, int dist_type, double sigma, GpuRngSeed seed) {
     ABI_GUARD_BEGIN
     if (!out) return set_error("gpu_matrix_sample_distribution: null matrix");

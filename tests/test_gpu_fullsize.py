@@ -154,3 +154,96 @@ def test_u64_row_vector_product_beyond_the_infinity_cache(gpu, oracle):
     assert (a1 + a2) * b == c1 + a2 * b
     for col in (0, 17, 39):
         assert a1 * b.slice_columns(col, col + 1) == c1.slice_columns(col, col + 1)
+
+
+@pytest.mark.parametrize("depth", [10, 8])  # M3A (benches/bench_preimage_gpu.rs:7-56) and M3B (BASELINE configs[3])
+def test_m3_whole_preimage_replays_on_the_cpu_at_full_size(gpu, oracle, depth):
+    """the bit-exact replay AT the bench shape - n = 2^14, L = 10 / 8, d = 1, all 50 target columns,
+    the large-operand assembly the bench times (stacked left factor over p2, NTT(z) + p2 through ntt14::fwd_add_kernel,
+    the top block from the output's own rows).  R, E, A and every residue of the 22 x 50 / 18 x 50 preimage equal
+    oracle.trapdoor_gen / oracle.preimage with the OS seeds replaced by fixed ones (test-only hook seed_source)."""
+    from mxx_amd.sampler import seed_source
+
+    p = make_params(gpu, oracle, N, depth, 24, 12)
+    moduli = p.moduli()
+    sigma, base, d, cols = 4.578, 12, 1, 50
+    master = bytes((11 * i + depth) & 0xFF for i in range(32))
+    seeds = [oracle._seed_from(master, i).tobytes() for i in range(6)]  # r, e, a_bar | p2, p1, z
+    r, e, a = oracle.trapdoor_gen(moduli, N, base, sigma, d, master)
+    target = oracle.matrix_ntt(oracle.random_matrix(770 + depth, d, cols, moduli, N), moduli)
+    want = oracle.preimage(moduli, N, base, sigma, r, e, a, target, master)
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, sigma)
+    with seed_source(seeds):
+        td, A = sampler.trapdoor(p, d)
+        assert np.array_equal(td.r.to_rns(), r) and np.array_equal(td.e.to_rns(), e) and np.array_equal(A.to_rns(), a)
+        gt = gpu.GpuDCRTPolyMatrix.from_rns(p, target, True)
+        n0 = p.ctx().last_kernel()
+        x = sampler.preimage(p, td, A, gt)
+    del n0
+    k = p.modulus_digits()
+    assert x.size() == (k + 2, cols) and x.is_ntt
+    got = x.to_rns()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert A * x == gt
+
+
+def test_m1_step_full_batch_against_the_oracle(gpu, oracle):
+    """BASELINE configs[1] at full size through the kernels bench.py times: x <- INTT(NTT(x) o w) on 1024 polys x 4
+    limbs - ntt14::fwd_kernel, then the fused product + inverse transform (gpupoly_matrix_mul_scalar_intt) - and 40
+    polynomials spread over the batch (first, last, every 27th) against oracle.matrix_ntt / oracle.pointwise."""
+    from mxx_amd import _ffi
+
+    p = make_params(gpu, oracle, N, 4, 24, 12)
+    moduli = p.moduli()
+    us = gpu.GpuDCRTPolyUniformSampler()
+    x = us.sample_uniform(p, 1024, 1, gpu.DistType.FinRingDist())
+    x.intt_all_in_place()
+    w = us.sample_uniform(p, 1, 1, gpu.DistType.FinRingDist())
+    rows = sorted(set([0, 1023] + list(range(5, 1024, 27))))
+    assert len(rows) >= 32
+    x_h = {r: x.slice_rows(r, r + 1).to_rns() for r in rows}  # COEFF
+    w_h = w.to_rns()
+    lib = _ffi.lib()
+    _ffi.check_status(lib.gpu_matrix_ntt_all(x.raw), "gpu_matrix_ntt_all")
+    x.is_ntt = True
+    ev = {r: x.slice_rows(r, r + 1).to_rns() for r in (0, 518, 1023)}
+    _ffi.check_status(lib.gpupoly_matrix_mul_scalar_intt(x.raw, x.raw, w.raw), "gpupoly_matrix_mul_scalar_intt")
+    x.is_ntt = False
+    for r in rows:
+        e = oracle.matrix_ntt(x_h[r], moduli)
+        if r in ev:
+            assert np.array_equal(ev[r], e), r
+        want = oracle.matrix_ntt(oracle.pointwise("mul", e, w_h, moduli), moduli, inverse=True)
+        assert np.array_equal(x.slice_rows(r, r + 1).to_rns(), want), r
+
+
+def test_m4_chain_step_replays_on_the_cpu_at_depth_12(gpu, oracle):
+    """BASELINE configs[4] parameters (n = 256, 12 limbs of 51 bits, base 2^17, d = 2) - the step bench.py's chain_m4 block
+    times: preimage of a 4-column target (bit for bit against oracle.preimage, fixed seeds), the encoding times the key,
+    and mul_decompose, each against the CPU restatement."""
+    from mxx_amd.sampler import seed_source
+
+    n, depth, bits, base, d = 256, 12, 51, 17, 2
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    k = p.modulus_digits()
+    master = bytes((5 * i + 1) & 0xFF for i in range(32))
+    seeds = [oracle._seed_from(master, i).tobytes() for i in range(6)]
+    r, e, a = oracle.trapdoor_gen(moduli, n, base, 4.578, d, master)
+    target = oracle.matrix_ntt(oracle.random_matrix(4004, d, 2 * d, moduli, n), moduli)
+    want = oracle.preimage(moduli, n, base, 4.578, r, e, a, target, master)
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, 4.578)
+    with seed_source(seeds):
+        td, A = sampler.trapdoor(p, d)
+        K = sampler.preimage(p, td, A, gpu.GpuDCRTPolyMatrix.from_rns(p, target, True))
+    assert np.array_equal(A.to_rns(), a)
+    assert np.array_equal(K.ensure_eval().to_rns(), want)
+    c0 = oracle.matrix_ntt(oracle.random_matrix(4005, 1, A.col_size(), moduli, n), moduli)
+    g0 = gpu.GpuDCRTPolyMatrix.from_rns(p, c0, True)
+    assert np.array_equal((g0 * K).to_rns(), oracle.matmul(c0, want, moduli))
+    B = oracle.matrix_ntt(oracle.random_matrix(4006, d, d * k, moduli, n), moduli)
+    M = oracle.random_matrix(4007, d, 3, moduli, n)  # COEFF
+    got = gpu.GpuDCRTPolyMatrix.from_rns(p, B, True).mul_decompose(gpu.GpuDCRTPolyMatrix.from_rns(p, oracle.matrix_ntt(M, moduli), True))
+    dec = oracle.matrix_ntt(oracle.decompose(M, moduli, base), moduli)
+    assert np.array_equal(got.to_rns(), oracle.matmul(B, dec, moduli))
