@@ -63,7 +63,20 @@ struct ChaChaRng {
 #define RNG_DRAW_MASK ((1u << RNG_DRAW_BITS) - 1u)
 #define RNG_BLOCK_DRAWS (512u / RNG_DRAW_BITS)               // draws per keystream block
 #define RNG_U64_DRAWS (64 / RNG_DRAW_BITS)
-#define RNG_URGENT (RNG_DRAW_BITS == 16 ? 20u : 30u)         // 8 steps + two service points
+// shape of a superstep of the persistent-lane kernels: KARNEY_SERVICES x [service point, KARNEY_LIGHTS cheap steps]
+// between two keystream checkpoints.  4 x 2 is the measured optimum (same-box sweep of 2x4, 3x2, 3x3, 4x2, 6x2, 8x1,
+// 12x1, 16x1 in profiles/r04_notes.md: more cheap steps per service point make the parked lanes wait longer than the
+// saved service executions are worth, fewer execute the service blocks - which the whole wave pays for - too often)
+#ifndef KARNEY_LIGHTS
+#define KARNEY_LIGHTS 4
+#endif
+#ifndef KARNEY_SERVICES
+#define KARNEY_SERVICES 2
+#endif
+#define KARNEY_SUPERSTEP (KARNEY_LIGHTS * KARNEY_SERVICES)
+// a lane is "urgent" when the draws it holds may not last to the next checkpoint: a superstep's cheap steps take one
+// draw each, a service point at most six
+#define RNG_URGENT (RNG_DRAW_BITS == 16 ? (KARNEY_SUPERSTEP + 6u * KARNEY_SERVICES > 31u ? 31u : KARNEY_SUPERSTEP + 6u * KARNEY_SERVICES) : 30u)
 #define RNG_STARVING (RNG_DRAW_BITS == 16 ? 6u : 12u)
 
 __host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
@@ -601,18 +614,34 @@ static __device__ int64_t sample_integer_karney(ChaChaRng &rng, double mean, dou
     return f.result;
 }
 
-// Elements per workgroup chunk for the persistent-lane kernels: one resident round of the whole
-// chip when the problem is big enough (chunks are consumed dynamically inside a workgroup, so the
-// only imbalance left is the last element of each lane).  MXX_HIP_SAMPLER_PER_LANE=n forces n
-// elements per lane (tests use it to exercise stream switching at small sizes).
+// Launch shape of the persistent-lane kernels (round 4).  A workgroup is ONE wave (SAMPLER_THREADS = 64) that owns a
+// chunk of 64 x per_lane elements, consumed dynamically by its lanes.  per_lane = enough to give every resident lane an
+// element, capped at kSamplerPerLaneCap: large problems then run as SEVERAL rounds of small workgroups instead of one
+// resident round of long ones.  Same-box sweeps (profiles/r04_notes.md), M3A call: one round of 256-thread workgroups at
+// 25 elements per lane 6.84-6.90 ms; capped at 8: 6.60; 64-thread workgroups capped at 8: 6.47-6.50 (cap 6: 6.48-6.50,
+// 12: 6.50-6.52, 16: 6.79-6.83); M4 step 0.621 -> 0.592; the 7-column shard (one rank's share of M3A at N = 8) 1.457 ->
+// 1.377.  A wave's SIMD slot and LDS go back to the dispatcher as soon as ITS lanes are done, not when the slowest of four
+// waves is; and the waves of a round start staggered, which spreads their keystream passes and service blocks in time.
+// A persistent one-round grid fed from a global chunk counter (no tail between a wave's chunks) was built and measured:
+// slower at the occupancy the runtime reports (6.93 ms: workgroups beyond the really resident ones hold their static first
+// chunks until the end), equal when oversubscribed (6.44) - removed.
+// MXX_HIP_SAMPLER_PER_LANE=n forces n elements per lane (tests exercise stream switching with it).
+#ifndef SAMPLER_PER_LANE_CAP
+#define SAMPLER_PER_LANE_CAP 8
+#endif
+constexpr uint32_t kSamplerPerLaneCap = SAMPLER_PER_LANE_CAP;
+// threads per workgroup of the persistent-lane kernels (a lane's ring is 128 bytes of LDS: 8 KB per wave)
+#ifndef SAMPLER_THREADS
+#define SAMPLER_THREADS 64
+#endif
 static inline uint32_t sampler_per_lane(size_t total, const void *kernel, int device, int forced) {
     if (forced >= 1) return static_cast<uint32_t>(forced);
     int blocks_per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) != hipSuccess || blocks_per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, SAMPLER_THREADS, 0) != hipSuccess || blocks_per_cu < 1)
         blocks_per_cu = 2;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
-    const size_t lanes = static_cast<size_t>(blocks_per_cu) * cus * 256u;
+    const size_t lanes = static_cast<size_t>(blocks_per_cu) * cus * SAMPLER_THREADS;
     const size_t per = (total + lanes - 1) / lanes;
-    return static_cast<uint32_t>(per < 1 ? 1 : (per > 4096 ? 4096 : per));
+    return static_cast<uint32_t>(per < 1 ? 1 : (per > kSamplerPerLaneCap ? kSamplerPerLaneCap : per));
 }
 

@@ -155,11 +155,11 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 #ifndef GAUSS_GROUP_LOG
 #define GAUSS_GROUP_LOG 1  // two coefficients per stream (the CPU restatement's keying: oracle/oracle_sampling.c)
 #endif
-__global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
+__global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every,
                                     int starve_limit) {
-    __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
+    __shared__ uint32_t ring[SAMPLER_THREADS * RNG_RING_SLOTS];  // 128 bytes per lane: 8 KB per one-wave workgroup
     const uint32_t glog = logN < GAUSS_GROUP_LOG ? logN : GAUSS_GROUP_LOG;
     const uint32_t G = 1u << glog;
     const size_t total = (polys << logN) >> glog;  // groups
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
             else karney_begin(f, 0.0, sigma, div);
         }
     };
-    for (uint32_t step = 0;; step += 8) {
+    for (uint32_t step = 0;; ++step) {  // one superstep per iteration
         integer_ready();
         {
             const bool take = f.st == KS_DONE && fin;
@@ -199,15 +199,18 @@ __global__ void __launch_bounds__(256) sample_gauss_kernel(int64_t *__restrict__
                 }
             }
             if (__all(f.st == KS_IDLE)) break;
-            rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0, starve_limit);
+            rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0, starve_limit);
         }
         karney_heavy(f, rng);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) karney_light(f, rng);
-        integer_ready();
-        karney_heavy(f, rng);
+        for (int s = 0; s < KARNEY_LIGHTS; ++s) karney_light(f, rng);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) karney_light(f, rng);
+        for (int sv = 1; sv < KARNEY_SERVICES; ++sv) {
+            integer_ready();
+            karney_heavy(f, rng);
+#pragma unroll
+            for (int s = 0; s < KARNEY_LIGHTS; ++s) karney_light(f, rng);
+        }
     }
 }
 
@@ -236,13 +239,13 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         if (polys >> 32) return set_error("gpu_matrix_sample_distribution: too many polynomials");
         const size_t groups = total >> (ctx->logN < GAUSS_GROUP_LOG ? ctx->logN : GAUSS_GROUP_LOG);
         const uint32_t per_lane = sampler_per_lane(groups, reinterpret_cast<const void *>(sample_gauss_kernel), ctx->device, ctx->env.sampler_per_lane);
-        const unsigned blocks = static_cast<unsigned>((groups + 256u * per_lane - 1) / (256u * per_lane));
+        const unsigned blocks = static_cast<unsigned>((groups + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
         const KarneyDivisor div = karney_divisor(sigma);
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
         MXX_TRACE_BYTES(static_cast<double>(total) * sizeof(int64_t));  // no input: the int64 samples written once
-        MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
+        MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
                            static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,
                            // one group per lane at most: the call lasts as long as its unluckiest lane's chain, which
                            // must not wait for keystream - refills at every checkpoint; otherwise every third and

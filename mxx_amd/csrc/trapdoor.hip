@@ -239,13 +239,13 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 // +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
 template <typename W, int MAXD>
-__global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage,
+__global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage,
                                         const LimbConst *__restrict__ limbs, ChaChaKey key,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
                                         uint32_t L, uint32_t logN, uint32_t dpt, uint32_t base_bits, double c,
                                         KarneyDivisor div_sigma, uint32_t per_lane, uint32_t fill_every) {
-    __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
+    __shared__ uint32_t ring[SAMPLER_THREADS * RNG_RING_SLOTS];  // 128 bytes per lane: 8 KB per one-wave workgroup
     const uint64_t base = 1ull << base_bits;
     const double base_f = static_cast<double>(base);
     const double sigma = c / (base_f + 1.0);
@@ -341,18 +341,21 @@ __global__ void __launch_bounds__(256, 4) gauss_samp_lanes_kernel(int64_t *__res
             }
         }
     };
-    for (uint32_t step = 0;; step += 8) {
+    for (uint32_t step = 0;; ++step) {  // one superstep per iteration
         integer_ready();
         element_done();
         if (__all(f.st == KS_IDLE)) break;
-        rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
+        rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0);
         karney_heavy(f, rng);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
-        integer_ready();
-        karney_heavy(f, rng);
+        for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
+        for (int sv = 1; sv < KARNEY_SERVICES; ++sv) {
+            integer_ready();
+            karney_heavy(f, rng);
+#pragma unroll
+            for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
+        }
     }
 }
 
@@ -418,10 +421,10 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
                        ctx->logN, dpt, base_bits, c);
     const uint32_t per_lane =
         sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device, ctx->env.sampler_per_lane);
-    const unsigned blocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));
+    const unsigned blocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * (8 - dpt) + 8.0 * dpt));  // pass 1's words read, dpt int64 digits written
-    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(256), 0, ctx->stream,
+    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream,
                        static_cast<int64_t *>(stage), ctx->d_limbs, key,
                        static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
                        base_bits, c, karney_divisor(sigma), per_lane,
@@ -616,12 +619,12 @@ __global__ void p1_divisor_kernel(KarneyDivisor *__restrict__ div, const double 
 // integers each (rows m-1 .. 0); integers go to the int64 staging array [row][col][N].  Keystream refills every
 // second checkpoint (fill_every; M3A: 0.47 -> 0.445 ms, every third 0.447)
 template <typename W, int MAXM>
-__global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ tp2,
+__global__ void __launch_bounds__(SAMPLER_THREADS) p1_sample_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ tp2,
                                        const double *__restrict__ sqrt_var_base, const double *__restrict__ update_base,
                                        const KarneyDivisor *__restrict__ div_base, uint32_t m, uint32_t cols, uint32_t L,
                                        uint32_t logN, uint64_t q0, double c_scale, ChaChaKey key, size_t total,
                                        uint32_t per_lane, uint32_t fill_every) {
-    __shared__ uint32_t ring[256 * RNG_RING_SLOTS];  // exactly 32 KB: five workgroups per CU
+    __shared__ uint32_t ring[SAMPLER_THREADS * RNG_RING_SLOTS];  // 128 bytes per lane: 8 KB per one-wave workgroup
     WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
@@ -682,18 +685,21 @@ __global__ void __launch_bounds__(256) p1_sample_lanes_kernel(int64_t *__restric
             }
         }
     };
-    for (uint32_t step = 0;; step += 8) {
+    for (uint32_t step = 0;; ++step) {  // one superstep per iteration
         integer_ready();
         element_done();
         if (__all(f.st == KS_IDLE)) break;
-        rng_fill_wave(rng, f.st != KS_IDLE, (step >> 3) % fill_every == 0);
+        rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0);
         karney_heavy(f, rng);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
-        integer_ready();
-        karney_heavy(f, rng);
+        for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) karney_light(f, rng);
+        for (int sv = 1; sv < KARNEY_SERVICES; ++sv) {
+            integer_ready();
+            karney_heavy(f, rng);
+#pragma unroll
+            for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
+        }
     }
 }
 
@@ -830,8 +836,8 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
     do {                                                                                                          \
         const uint32_t per_lane =                                                                                 \
             sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM>), ctx->device, ctx->env.sampler_per_lane); \
-        const unsigned lblocks = static_cast<unsigned>((total + 256u * per_lane - 1) / (256u * per_lane));        \
-        MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(256), 0, ctx->stream,          \
+        const unsigned lblocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane)); \
+        MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(SAMPLER_THREADS), 0, ctx->stream, \
                            static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,    \
                            cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m, \
                            (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,           \
