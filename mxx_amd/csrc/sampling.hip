@@ -214,6 +214,145 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
     }
 }
 
+// ---- MXX_HIP_RNG_COMPAT=reference: the reference device RNG's own keying -----------------------
+// The default keying departs from cuda/src/ChaCha.cu:138-149 + cuda/src/matrix/MatrixSampling.cu:239-289 in three
+// documented ways (rng.h), so a matrix derived from a seed - the hash sampler's included - differs from the one a CUDA
+// build derives.  With the switch set (read per context at creation, gpupoly_reload_env) gpu_matrix_sample_distribution
+// and _columns key and consume their streams exactly as the reference does: a stream per (polynomial, coefficient) -
+// and limb, for the uniform distribution -, stream0 in the 64-bit block counter, stream1 in the nonce, 64-bit draws, Karney
+// on 53-bit deviates compared as doubles.  One thread per coefficient, nested loops: the slow path, for interoperability
+// only.  Pure function of (seed, global polynomial index, coefficient, limb) as before: column windows commute.
+struct RefRng {
+    uint32_t state[16], block[16];
+    uint32_t idx;
+};
+
+__device__ __forceinline__ void ref_rng_init(RefRng &r, const GpuRngSeed &seed, uint64_t s0, uint64_t s1, uint64_t s2, uint64_t tag) {
+    const ChaChaKey k = chacha_subkey(seed, s2, tag);
+    r.state[0] = 0x61707865u; r.state[1] = 0x3320646eu; r.state[2] = 0x79622d32u; r.state[3] = 0x6b206574u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.state[4 + i] = k.w[i];
+    r.state[12] = static_cast<uint32_t>(s0);
+    r.state[13] = static_cast<uint32_t>(s0 >> 32);
+    r.state[14] = static_cast<uint32_t>(s1);
+    r.state[15] = static_cast<uint32_t>(s1 >> 32);
+    r.idx = 8;
+}
+
+__device__ __noinline__ void ref_rng_refill(RefRng &r) {
+    uint32_t x[16];
+    for (int i = 0; i < 16; ++i) x[i] = r.state[i];
+    chacha_rounds(x);
+    for (int i = 0; i < 16; ++i) r.block[i] = x[i] + r.state[i];
+    if (++r.state[12] == 0) ++r.state[13];
+    r.idx = 0;
+}
+
+__device__ __forceinline__ uint64_t ref_rng_u64(RefRng &r) {
+    if (r.idx >= 8) ref_rng_refill(r);
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t i = 0; i < 8; ++i)  // register-resident block: select instead of indexing
+        if (i == r.idx) { lo = r.block[2 * i]; hi = r.block[2 * i + 1]; }
+    ++r.idx;
+    return static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+}
+
+__device__ __forceinline__ double ref_rng_u01(RefRng &r) { return u64_to_open01(ref_rng_u64(r)); }
+
+__device__ bool ref_karney_h(RefRng &r) {
+    double a = ref_rng_u01(r);
+    if (!(a < 0.5)) return true;
+    for (;;) {
+        const double b = ref_rng_u01(r);
+        if (!(b < a)) return false;
+        a = ref_rng_u01(r);
+        if (!(a < b)) return true;
+    }
+}
+
+__device__ bool ref_karney_b(RefRng &r, int32_t k, double x) {
+    double y = x;
+    int32_t n = 0;
+    const double m = static_cast<double>(2 * k + 2);
+    for (;; ++n) {
+        const double z = ref_rng_u01(r);
+        if (!(z < y)) break;
+        const double t = ref_rng_u01(r);
+        if (!(t < (2.0 * static_cast<double>(k) + x) / m)) break;
+        y = z;
+        if (n > 4096) break;
+    }
+    return (n % 2) == 0;
+}
+
+__device__ int64_t ref_karney(RefRng &r, double mean, double stddev) {
+    if (!(stddev > 0.0) || !isfinite(mean) || !isfinite(stddev)) return static_cast<int64_t>(llround(mean));
+    const int64_t cs = static_cast<int64_t>(ceil(stddev));
+    if (cs <= 0) return static_cast<int64_t>(llround(mean));
+    for (int iter = 0; iter < (1 << 16); ++iter) {
+        int32_t k = 0;
+        while (ref_karney_h(r)) {
+            if (++k > 1024) break;
+        }
+        int32_t n = k * (k - 1);
+        while (n-- && ref_karney_h(r)) {
+        }
+        if (!(n < 0)) continue;
+        const int64_t s = (ref_rng_u64(r) & 1ull) ? 1 : -1;
+        const double di0 = stddev * static_cast<double>(k) + static_cast<double>(s) * mean;
+        const int64_t i0 = static_cast<int64_t>(ceil(di0));
+        const double x0 = (static_cast<double>(i0) - di0) / stddev;
+        const int64_t j = static_cast<int64_t>(ref_rng_u64(r) % static_cast<uint64_t>(cs));
+        const double x = x0 + static_cast<double>(j) / stddev;
+        if (!(x < 1.0) || (x == 0.0 && s < 0 && k == 0)) continue;
+        int32_t h = k + 1;
+        while (h-- > 0 && ref_karney_b(r, k, x)) {
+        }
+        if (h >= 0) continue;
+        return s * (i0 + j);
+    }
+    // 2^16 rejected trials: not reachable in practice (the reference falls back to a rounded normal here)
+    const double u1 = ref_rng_u01(r), u2 = ref_rng_u01(r);
+    return static_cast<int64_t>(llround(mean + stddev * (sqrt(-2.0 * det_log(u1)) * det_cos2pi(u2))));
+}
+
+template <typename W>
+__global__ void __launch_bounds__(128) sample_compat_kernel(W *__restrict__ out, const LimbConst *__restrict__ limbs, size_t polys,
+                                                            size_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t L,
+                                                            uint32_t logN, int dist, double sigma, GpuRngSeed seed) {
+    const size_t idx = item_index();
+    if (idx >= (polys << logN)) return;
+    const size_t p = idx >> logN;
+    const uint32_t i = static_cast<uint32_t>(idx & ((size_t(1) << logN) - 1));
+    const size_t row = p / local_ncol, lcol = p - row * local_ncol;
+    const uint64_t gpoly = row * full_ncol + col_offset + lcol;
+    RefRng r;
+    if (dist == GPU_MATRIX_DIST_UNIFORM) {
+        for (uint32_t l = 0; l < L; ++l) {
+            const uint64_t q = limbs[l].q, threshold = ~0ull - (~0ull % q);
+            ref_rng_init(r, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, static_cast<uint64_t>(l) + 1, kTagUniform);
+            uint64_t x;
+            do x = ref_rng_u64(r); while (x >= threshold);
+            out[((p * L + l) << logN) + i] = static_cast<W>(x % q);
+        }
+        return;
+    }
+    int64_t z;
+    if (dist == GPU_MATRIX_DIST_GAUSS) {
+        ref_rng_init(r, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagGauss);
+        z = ref_karney(r, 0.0, sigma);
+    } else if (dist == GPU_MATRIX_DIST_BIT) {
+        ref_rng_init(r, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagBit);
+        z = static_cast<int64_t>(ref_rng_u64(r) & 1ull);
+    } else {
+        ref_rng_init(r, seed, gpoly + 1, static_cast<uint64_t>(i) + 1, 0, kTagTernary);
+        const uint64_t pick = ref_rng_u64(r) % 3ull;
+        z = pick == 0 ? 0 : (pick == 1 ? 1 : -1);
+    }
+    for (uint32_t l = 0; l < L; ++l)
+        out[((p * L + l) << logN) + i] = signed_to_residue_mu<W>(z, limbs[l].q, limbs[l].mu64);
+}
+
 // keep_coeff: leave the samples as coefficients (for a caller that decomposes them next) instead of finishing in EVAL
 int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t full_ncol, size_t col_offset, bool keep_coeff) {
     if (!out) return set_error("gpu_matrix_sample_distribution: null matrix");
@@ -234,6 +373,19 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
     const size_t total = polys * static_cast<size_t>(ctx->N);
     const uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
     const uint32_t N = static_cast<uint32_t>(ctx->N);
+    if (ctx->env.rng_compat) {
+        const dim3 blocks = item_grid(total, 128);
+        MXX_TRACE_BYTES(static_cast<double>(out->bytes));
+        if (ctx->wide)
+            MXX_LAUNCH(sample_compat_kernel<uint64_t>, blocks, dim3(128), 0, ctx->stream, static_cast<uint64_t *>(out->data), ctx->d_limbs,
+                       polys, out->cols, full_ncol, col_offset, L, ctx->logN, dist, sigma, seed);
+        else
+            MXX_LAUNCH(sample_compat_kernel<uint32_t>, blocks, dim3(128), 0, ctx->stream, static_cast<uint32_t *>(out->data), ctx->d_limbs,
+                       polys, out->cols, full_ncol, col_offset, L, ctx->logN, dist, sigma, seed);
+        HIP_TRY(hipGetLastError());
+        if (keep_coeff) return 0;
+        return launch_ntt(ctx, out->data, polys * L, static_cast<int>(L), false);
+    }
     if (dist == GPU_MATRIX_DIST_GAUSS) {
         // enough lanes to fill the chip first, then up to 16 coefficients per lane
         if (polys >> 32) return set_error("gpu_matrix_sample_distribution: too many polynomials");

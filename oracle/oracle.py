@@ -142,6 +142,8 @@ def _bind_sampling(L):
         _u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u64p,
         C.c_int, C.c_double, _u64p,
     ]
+    L.orc_sample_distribution_refkey.restype = None
+    L.orc_sample_distribution_refkey.argtypes = L.orc_sample_distribution.argtypes
     L.orc_karney.restype = None
     L.orc_karney.argtypes = [_u64p, C.c_uint64, C.c_double, C.c_double, _i64p, C.c_size_t]
     L.orc_karney_ties.restype = C.c_ulonglong
@@ -365,6 +367,17 @@ def sample_distribution(rows, cols, moduli, n, dist: str, sigma, seed, full_ncol
     out = np.zeros((rows, cols, L, n), dtype=np.uint64)
     full = cols if full_ncol is None else full_ncol
     lib().orc_sample_distribution(_p(out), rows, cols, full, col_offset, L, n, _p(_mod(moduli)), DIST[dist], float(sigma), _p(_seed_words(seed)))
+    return out
+
+
+def sample_distribution_refkey(rows, cols, moduli, n, dist: str, sigma, seed, full_ncol=None, col_offset=0) -> np.ndarray:
+    """The same call with the reference device RNG's OWN keying (cuda/src/ChaCha.cu:104-167, MatrixSampling.cu:239-289):
+    what libgpupoly must produce under MXX_HIP_RNG_COMPAT=reference."""
+    L = len(moduli)
+    out = np.zeros((rows, cols, L, n), dtype=np.uint64)
+    full = cols if full_ncol is None else full_ncol
+    lib().orc_sample_distribution_refkey(_p(out), rows, cols, full, col_offset, L, n, _p(_mod(moduli)), DIST[dist], float(sigma),
+                                         _p(_seed_words(seed)))
     return out
 
 

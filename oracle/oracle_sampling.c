@@ -298,6 +298,135 @@ void orc_sample_distribution(uint64_t *out, size_t rows, size_t local_ncol, size
     }
 }
 
+/* ---- the reference device RNG's OWN keying (MXX_HIP_RNG_COMPAT=reference) ----------------------------------------
+ * Restates cuda/src/ChaCha.cu:104-167 and cuda/src/matrix/MatrixSampling.cu:6-147,239-289 as they stand, i.e. WITHOUT the
+ * three departures documented in mxx_amd/csrc/rng.h: stream0 is the 64-bit block counter (state words 12, 13), stream1
+ * the nonce (words 14, 15), a stream per (polynomial, coefficient[, limb]), 64-bit draws, 53-bit uniform deviates compared
+ * as doubles.  With the switch set the library's gpu_matrix_sample_distribution(_columns) must produce these samples:
+ * a matrix derived from a seed is then the one a CUDA build of the reference derives from it. */
+typedef struct {
+    uint32_t state[16], block[16];
+    uint32_t idx; /* next 64-bit word of the block, 8 = empty */
+} ref_rng_t;
+
+static void ref_init(ref_rng_t *r, const uint64_t seed[4], uint64_t s0, uint64_t s1, uint64_t s2, uint64_t tag) {
+    rng_t k;
+    rng_init(&k, seed, 0, 0, s2, tag); /* the HChaCha20 sub-key is the same function of (seed, tag, stream2) */
+    memcpy(r->state, k.state, 12 * sizeof(uint32_t));
+    r->state[12] = (uint32_t)s0; r->state[13] = (uint32_t)(s0 >> 32); /* ChaCha.cu:138-149: the counter IS stream0 */
+    r->state[14] = (uint32_t)s1; r->state[15] = (uint32_t)(s1 >> 32);
+    r->idx = 8;
+}
+
+static uint64_t ref_u64(ref_rng_t *r) {
+    if (r->idx >= 8) {
+        orc_chacha20_block(r->state, r->block);
+        if (++r->state[12] == 0) ++r->state[13];
+        r->idx = 0;
+    }
+    const uint64_t v = (uint64_t)r->block[2 * r->idx] | ((uint64_t)r->block[2 * r->idx + 1] << 32);
+    ++r->idx;
+    return v;
+}
+
+static double ref_u01(ref_rng_t *r) {
+    const double scale = 1.0 / 9007199254740992.0;
+    double u = (double)(ref_u64(r) >> 11) * scale;
+    if (u <= 0.0) u = scale;
+    else if (u >= 1.0) u = 1.0 - scale;
+    return u;
+}
+
+static int ref_h(ref_rng_t *r) { /* MatrixSampling.cu:30-50 */
+    double a = ref_u01(r);
+    if (!(a < 0.5)) return 1;
+    for (;;) {
+        const double b = ref_u01(r);
+        if (!(b < a)) return 0;
+        a = ref_u01(r);
+        if (!(a < b)) return 1;
+    }
+}
+
+static int ref_b(ref_rng_t *r, int32_t k, double x) { /* :74-96 */
+    double y = x;
+    int32_t n = 0;
+    const double m = (double)(2 * k + 2);
+    for (;; ++n) {
+        const double z = ref_u01(r);
+        if (!(z < y)) break;
+        const double t = ref_u01(r);
+        if (!(t < (2.0 * (double)k + x) / m)) break;
+        y = z;
+        if (n > 4096) break;
+    }
+    return (n % 2) == 0;
+}
+
+static int64_t ref_karney(ref_rng_t *r, double mean, double stddev) { /* :98-147 */
+    if (!(stddev > 0.0) || !isfinite(mean) || !isfinite(stddev)) return (int64_t)llround(mean);
+    const int64_t cs = (int64_t)ceil(stddev);
+    if (cs <= 0) return (int64_t)llround(mean);
+    for (int iter = 0; iter < (1 << 16); ++iter) {
+        int32_t k = 0;
+        while (ref_h(r)) {
+            if (++k > 1024) break;
+        }
+        int32_t n = k * (k - 1);
+        while (n-- && ref_h(r)) {
+        }
+        if (!(n < 0)) continue;
+        const int64_t s = (ref_u64(r) & 1ull) ? 1 : -1;
+        const double di0 = stddev * (double)k + (double)s * mean;
+        const int64_t i0 = (int64_t)ceil(di0);
+        const double x0 = ((double)i0 - di0) / stddev;
+        const int64_t j = (int64_t)(ref_u64(r) % (uint64_t)cs);
+        const double x = x0 + (double)j / stddev;
+        if (!(x < 1.0) || (x == 0.0 && s < 0 && k == 0)) continue;
+        int32_t h = k + 1;
+        while (h-- > 0 && ref_b(r, k, x)) {
+        }
+        if (h >= 0) continue;
+        return s * (i0 + j);
+    }
+    const double u1 = ref_u01(r), u2 = ref_u01(r); /* never reached in practice; libm here, as the reference */
+    return (int64_t)llround(mean + stddev * (sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2)));
+}
+
+/* same layout as orc_sample_distribution; keys of MatrixSampling.cu:239-289 */
+void orc_sample_distribution_refkey(uint64_t *out, size_t rows, size_t local_ncol, size_t full_ncol, size_t col_offset,
+                                    uint32_t L, uint32_t n, const uint64_t *moduli, int dist, double sigma,
+                                    const uint64_t *seed) {
+    long total = (long)(rows * local_ncol);
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < total; ++p) {
+        size_t row = (size_t)p / local_ncol, lcol = (size_t)p % local_ncol;
+        uint64_t gpoly = row * full_ncol + col_offset + lcol;
+        for (uint32_t i = 0; i < n; ++i) {
+            ref_rng_t r;
+            if (dist == 0) {
+                for (uint32_t l = 0; l < L; ++l) {
+                    const uint64_t q = moduli[l], max = ~0ull, threshold = max - (max % q);
+                    ref_init(&r, seed, gpoly + 1, (uint64_t)i + 1, (uint64_t)l + 1, 0x6f70656e66686531ull);
+                    uint64_t x;
+                    do x = ref_u64(&r); while (x >= threshold);
+                    out[((size_t)p * L + l) * n + i] = x % q;
+                }
+                continue;
+            }
+            int64_t z;
+            ref_init(&r, seed, gpoly + 1, (uint64_t)i + 1, 0, 0x6f70656e66686531ull + (uint64_t)dist);
+            if (dist == 1) z = ref_karney(&r, 0.0, sigma);
+            else if (dist == 2) z = (int64_t)(ref_u64(&r) & 1ull);
+            else {
+                const uint64_t pick = ref_u64(&r) % 3ull;
+                z = pick == 0 ? 0 : (pick == 1 ? 1 : -1);
+            }
+            for (uint32_t l = 0; l < L; ++l) out[((size_t)p * L + l) * n + i] = signed_mod(z, moduli[l]);
+        }
+    }
+}
+
 static inline uint32_t bit_width(uint64_t v) { return v ? 64 - (uint32_t)__builtin_clzll(v) : 0; }
 
 /* G-lattice sampling, COEFF in (rows x cols) -> COEFF out (rows*k x cols), k = dpt*L. */

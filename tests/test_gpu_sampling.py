@@ -352,3 +352,46 @@ def test_sample_decomposed_extension_equals_sample_then_decompose(gpu, oracle, n
         assert full == a.decompose()
         assert small == a.small_decompose()
     assert hs.sample_hash_decomposed(p, key, b"dec", 0, 3, gpu.DistType.BitDist()).size() == (0, 3)
+
+
+@pytest.mark.parametrize("n,depth,bits,base", [(16, 3, 18, 6), (1024, 2, 24, 12), (64, 2, 51, 17)])
+@pytest.mark.parametrize("dist,sigma", [("uniform", 0.0), ("gauss", 4.578), ("gauss", 8191.5), ("bit", 0.0), ("ternary", 0.0)])
+def test_rng_compat_reference_keying(gpu, oracle, hip_env, n, depth, bits, base, dist, sigma):
+    """MXX_HIP_RNG_COMPAT=reference: gpu_matrix_sample_distribution(_columns) keyed and consumed
+    exactly as the reference's device RNG (cuda/src/ChaCha.cu:104-167, cuda/src/matrix/MatrixSampling.cu:30-147,239-289) -
+    bit for bit against the CPU restatement of that keying; column windows still commute (src/sampler/gpu.rs:323-361);
+    with the switch unset the default keying is back, and the two differ."""
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    moduli = p.moduli()
+    s = seed(gpu, 21)
+    code = oracle.DIST[dist]
+    default = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, code, sigma, s)
+    hip_env.set("MXX_HIP_RNG_COMPAT", "reference")
+    m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, code, sigma, s)
+    assert m.is_ntt
+    want = oracle.sample_distribution_refkey(2, 3, moduli, n, dist, sigma, s)
+    assert np.array_equal(m.to_coeff_rns(), want)
+    w = gpu.GpuDCRTPolyMatrix.sample_distribution_columns(p, 2, 3, 1, 2, code, sigma, s)
+    assert w == m.slice(0, 2, 1, 3)
+    assert not (m == default)
+    hip_env.unset("MXX_HIP_RNG_COMPAT")
+    assert gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 3, code, sigma, s) == default
+    assert np.array_equal(default.to_coeff_rns(), oracle.sample_distribution(2, 3, moduli, n, dist, sigma, s))
+
+
+def test_rng_compat_hash_sampler_and_preimage_predicates(gpu, oracle, hip_env):
+    """the callers of the seeded sampler under the reference keying: the hash sampler stays deterministic and window-
+    consistent, trapdoor generation and a preimage keep their exact predicates (R, E, p2 come from the compat sampler)"""
+    hip_env.set("MXX_HIP_RNG_COMPAT", "reference")
+    p = make_params(gpu, oracle, 256, 2, 24, 12)
+    hs = gpu.GpuDCRTPolyHashSampler()
+    key = bytes(range(32))
+    a = hs.sample_hash(p, key, b"tag", 2, 4, gpu.DistType.FinRingDist())
+    assert a == hs.sample_hash(p, key, b"tag", 2, 4, gpu.DistType.FinRingDist())
+    assert hs.sample_hash_columns(p, key, b"tag", 2, 4, 1, 2, gpu.DistType.FinRingDist()) == a.slice(0, 2, 1, 3)
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, 4.578)
+    td, A = sampler.trapdoor(p, 1)
+    k = p.modulus_digits()
+    assert A * td.r.concat_rows([td.e, gpu.GpuDCRTPolyMatrix.identity(p, k)]) == gpu.GpuDCRTPolyMatrix.gadget_matrix(p, 1)
+    target = gpu.GpuDCRTPolyUniformSampler().sample_uniform(p, 1, 3, gpu.DistType.FinRingDist())
+    assert A * sampler.preimage(p, td, A, target) == target

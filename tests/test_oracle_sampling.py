@@ -184,3 +184,55 @@ def test_karney_lazy_deviates_tie_path_is_exercised_and_unbiased():
     assert 30 <= ties <= 400, ties   # ~17 comparisons per integer / 65536
     assert abs(x.mean() - 0.37) < 0.03
     assert abs(x.std() - 4.578) < 0.03
+
+
+def test_reference_keyed_sampler_restates_the_reference_layout():
+    """oracle.sample_distribution_refkey (what MXX_HIP_RNG_COMPAT=reference must reproduce): the keying of
+    cuda/src/ChaCha.cu:104-167 + cuda/src/matrix/MatrixSampling.cu:239-289 recomputed HERE from raw ChaCha20 blocks - the
+    HChaCha20 sub-key of (seed, tag, stream2), stream0 = global polynomial index + 1 in the 64-bit block counter, stream1
+    = coefficient + 1 in the nonce, first 64-bit word of the first block - for the uniform (with its rejection loop), bit
+    and ternary distributions; column windows commute; the default keying gives a different matrix."""
+    import ctypes as C
+
+    n, moduli = 16, O.gen_crt_basis(16, 2, 17)
+    seed = O._seed_words(SEED)
+
+    def first_words(gpoly, coeff, stream2, tag, count):
+        x = np.zeros(16, dtype=np.uint32)
+        x[:4] = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]
+        for i in range(4):
+            x[4 + 2 * i], x[5 + 2 * i] = int(seed[i]) & 0xFFFFFFFF, int(seed[i]) >> 32
+        x[12], x[13], x[14], x[15] = tag & 0xFFFFFFFF, tag >> 32, stream2 & 0xFFFFFFFF, stream2 >> 32
+        # HChaCha20 = the block function without the feed-forward: out - in
+        blk = O.chacha20_block(x)
+        h = (blk.astype(np.uint64) - x.astype(np.uint64)) & 0xFFFFFFFF
+        st = np.zeros(16, dtype=np.uint32)
+        st[:4] = x[:4]
+        st[4:8], st[8:12] = h[0:4], h[12:16]
+        out, ctr = [], gpoly + 1
+        while len(out) < count:
+            st[12], st[13], st[14], st[15] = ctr & 0xFFFFFFFF, ctr >> 32, (coeff + 1) & 0xFFFFFFFF, (coeff + 1) >> 32
+            b = O.chacha20_block(st)
+            out += [int(b[2 * j]) | (int(b[2 * j + 1]) << 32) for j in range(8)]
+            ctr += 1
+        return out[:count]
+
+    full = {d: O.sample_distribution_refkey(2, 3, moduli, n, d, 0.0, SEED) for d in ("uniform", "bit", "ternary")}
+    for row, col, i in ((0, 0, 0), (1, 2, 15), (0, 1, 7)):
+        gpoly = row * 3 + col
+        for l, q in enumerate(moduli):
+            ws = first_words(gpoly, i, l + 1, 0x6F70656E66686531, 16)
+            thr = (2**64 - 1) - ((2**64 - 1) % q)
+            want = next(w for w in ws if w < thr) % q
+            assert int(full["uniform"][row, col, l, i]) == want
+        w = first_words(gpoly, i, 0, 0x6F70656E66686533, 1)[0]
+        assert int(full["bit"][row, col, 0, i]) == (w & 1)
+        w = first_words(gpoly, i, 0, 0x6F70656E66686534, 1)[0] % 3
+        assert int(O.centered(full["ternary"][row, col, 0], moduli[0])[i]) == (0 if w == 0 else (1 if w == 1 else -1))
+    for d, sigma in (("uniform", 0.0), ("gauss", 4.578), ("bit", 0.0), ("ternary", 0.0)):
+        a = O.sample_distribution_refkey(2, 5, moduli, n, d, sigma, SEED)
+        win = O.sample_distribution_refkey(2, 2, moduli, n, d, sigma, SEED, full_ncol=5, col_offset=2)
+        assert np.array_equal(win, a[:, 2:4])  # src/sampler/gpu.rs:323-361
+        assert not np.array_equal(a, O.sample_distribution(2, 5, moduli, n, d, sigma, SEED))
+    g = O.centered(O.sample_distribution_refkey(4, 4, moduli, 64, "gauss", 4.578, SEED)[:, :, 0], moduli[0]).astype(np.float64)
+    assert abs(g.mean()) < 0.5 and 4.0 < g.std() < 5.2
