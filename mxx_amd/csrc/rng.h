@@ -74,6 +74,14 @@ struct ChaChaRng {
 #define KARNEY_SERVICES 2
 #endif
 #define KARNEY_SUPERSTEP (KARNEY_LIGHTS * KARNEY_SERVICES)
+// Launches with at most one element per lane (the small rings of the GGH15 chain, a few target columns) last as long as
+// their unluckiest lane's chain of dependent steps, and almost every service block of such a wave serves one or two lanes:
+// they take the superstep with ONE service point per KARNEY_SUPERSTEP cheap steps (same-box: M4 step 0.592 -> 0.567 ms,
+// 1-2 target columns of M3A 0.61 / 0.78 -> 0.58 / 0.74 ms; large launches lose 2-3 % with it).  SV = services per
+// superstep is a template parameter of the lane kernels; the launchers pick it from per_lane.
+constexpr uint32_t karney_urgent(int services) {
+    return KARNEY_SUPERSTEP + 6u * services > 31u ? 31u : KARNEY_SUPERSTEP + 6u * services;
+}
 // a lane is "urgent" when the draws it holds may not last to the next checkpoint: a superstep's cheap steps take one
 // draw each, a service point at most six
 #define RNG_URGENT (RNG_DRAW_BITS == 16 ? (KARNEY_SUPERSTEP + 6u * KARNEY_SERVICES > 31u ? 31u : KARNEY_SUPERSTEP + 6u * KARNEY_SERVICES) : 30u)
@@ -226,10 +234,11 @@ __device__ __forceinline__ void rng_fill_lane(ChaChaRng &rng) {
 #ifndef MXX_FILL_POLICY
 #define MXX_FILL_POLICY 0
 #endif
-__device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool scheduled = true, int starve_limit = 16) {
+__device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool scheduled = true, int starve_limit = 16,
+                                              uint32_t urgent = RNG_URGENT) {
 #if MXX_FILL_POLICY == 0
     const uint32_t avail = rng.tail - rng.head;
-    const bool pass = (scheduled && __any(live && avail <= RNG_URGENT)) || __popcll(__ballot(live && avail < RNG_STARVING)) >= starve_limit;
+    const bool pass = (scheduled && __any(live && avail <= urgent)) || __popcll(__ballot(live && avail < RNG_STARVING)) >= starve_limit;
     if (pass && live && avail <= RNG_BLOCK_DRAWS) rng_block_lane<10>(rng);
 #else
     const uint32_t lane = threadIdx.x & 63u;
@@ -244,7 +253,7 @@ __device__ __forceinline__ void rng_fill_wave(ChaChaRng &rng, bool live, bool sc
             if (want) rng_block_lane<10>(rng);
             break;
         }
-        if (n < 16 && !__any(live && avail <= RNG_URGENT)) break;
+        if (n < 16 && !__any(live && avail <= urgent)) break;
         // requester with rank r < 16 announces itself to lane 4r (everyone else writes to an odd lane nobody reads)
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mw >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mw), 0u));
         const bool served = want && rank < 16u;

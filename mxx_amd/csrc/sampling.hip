@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 #ifndef GAUSS_GROUP_LOG
 #define GAUSS_GROUP_LOG 1  // two coefficients per stream (the CPU restatement's keying: oracle/oracle_sampling.c)
 #endif
+template <int SV>
 __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every,
@@ -199,17 +200,17 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
                 }
             }
             if (__all(f.st == KS_IDLE)) break;
-            rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0, starve_limit);
+            rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0, starve_limit, karney_urgent(SV));
         }
         karney_heavy(f, rng);
 #pragma unroll
-        for (int s = 0; s < KARNEY_LIGHTS; ++s) karney_light(f, rng);
+        for (int s = 0; s < KARNEY_SUPERSTEP / SV; ++s) karney_light(f, rng);
 #pragma unroll
-        for (int sv = 1; sv < KARNEY_SERVICES; ++sv) {
+        for (int sv = 1; sv < SV; ++sv) {
             integer_ready();
             karney_heavy(f, rng);
 #pragma unroll
-            for (int s = 0; s < KARNEY_LIGHTS; ++s) karney_light(f, rng);
+            for (int s = 0; s < KARNEY_SUPERSTEP / SV; ++s) karney_light(f, rng);
         }
     }
 }
@@ -390,20 +391,24 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         // enough lanes to fill the chip first, then up to 16 coefficients per lane
         if (polys >> 32) return set_error("gpu_matrix_sample_distribution: too many polynomials");
         const size_t groups = total >> (ctx->logN < GAUSS_GROUP_LOG ? ctx->logN : GAUSS_GROUP_LOG);
-        const uint32_t per_lane = sampler_per_lane(groups, reinterpret_cast<const void *>(sample_gauss_kernel), ctx->device, ctx->env.sampler_per_lane);
+        const uint32_t per_lane = sampler_per_lane(groups, reinterpret_cast<const void *>(sample_gauss_kernel<KARNEY_SERVICES>), ctx->device, ctx->env.sampler_per_lane);
         const unsigned blocks = static_cast<unsigned>((groups + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
         const KarneyDivisor div = karney_divisor(sigma);
         const ChaChaKey key = chacha_subkey(seed, 0, kTagGauss);
         void *stage = nullptr;
         if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
         MXX_TRACE_BYTES(static_cast<double>(total) * sizeof(int64_t));  // no input: the int64 samples written once
-        MXX_LAUNCH(sample_gauss_kernel, dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream, static_cast<int64_t *>(stage), polys,
-                           static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,
-                           // one group per lane at most: the call lasts as long as its unluckiest lane's chain, which
-                           // must not wait for keystream - refills at every checkpoint; otherwise every third and
-                           // never forced (64 lanes cannot reach 65)
-                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : (per_lane == 1 ? 1 : 3)),
-                           per_lane == 1 ? 1 : 65);
+        // one group per lane at most: the call lasts as long as its unluckiest lane's chain, which must not wait for
+        // keystream - refills at every checkpoint, one service point per superstep; otherwise every third checkpoint and
+        // never forced (64 lanes cannot reach 65)
+#define LAUNCH_SG(SV)                                                                                                          \
+    MXX_LAUNCH(sample_gauss_kernel<SV>, dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream, static_cast<int64_t *>(stage), polys, \
+               static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,                   \
+               static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : (per_lane == 1 ? 1 : 3)),      \
+               per_lane == 1 ? 1 : 65)
+        if (per_lane == 1) LAUNCH_SG(1);
+        else LAUNCH_SG(KARNEY_SERVICES);
+#undef LAUNCH_SG
         const hipError_t err = hipGetLastError();
         const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
         ctx_free(ctx, stage);

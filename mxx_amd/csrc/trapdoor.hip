@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 // Pass 2: the dpt Karney integers of every element.  Wave w owns elements [w*64*per_lane,
 // +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
-template <typename W, int MAXD>
+template <typename W, int MAXD, int SV>
 __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage,
                                         const LimbConst *__restrict__ limbs, ChaChaKey key,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
@@ -345,16 +345,16 @@ __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(in
         integer_ready();
         element_done();
         if (__all(f.st == KS_IDLE)) break;
-        rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0);
+        rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0, 16, karney_urgent(SV));
         karney_heavy(f, rng);
 #pragma unroll
-        for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
+        for (int s4 = 0; s4 < KARNEY_SUPERSTEP / SV; ++s4) karney_light(f, rng);
 #pragma unroll
-        for (int sv = 1; sv < KARNEY_SERVICES; ++sv) {
+        for (int sv = 1; sv < SV; ++sv) {
             integer_ready();
             karney_heavy(f, rng);
 #pragma unroll
-            for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
+            for (int s4 = 0; s4 < KARNEY_SUPERSTEP / SV; ++s4) karney_light(f, rng);
         }
     }
 }
@@ -420,15 +420,18 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
                        ctx->stream, a_words, left_words, src, ctx->d_limbs, key, total, L,
                        ctx->logN, dpt, base_bits, c);
     const uint32_t per_lane =
-        sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD>), ctx->device, ctx->env.sampler_per_lane);
+        sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD, KARNEY_SERVICES>), ctx->device, ctx->env.sampler_per_lane);
     const unsigned blocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * (8 - dpt) + 8.0 * dpt));  // pass 1's words read, dpt int64 digits written
-    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream,
-                       static_cast<int64_t *>(stage), ctx->d_limbs, key,
-                       static_cast<const GqTower *>(towers), a_words, left_words, total, src_cols, L, ctx->logN, dpt,
-                       base_bits, c, karney_divisor(sigma), per_lane,
-                       static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3));
+#define LAUNCH_GL(SV)                                                                                                       \
+    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD, SV>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream,                 \
+               static_cast<int64_t *>(stage), ctx->d_limbs, key, static_cast<const GqTower *>(towers), a_words, left_words, \
+               total, src_cols, L, ctx->logN, dpt, base_bits, c, karney_divisor(sigma), per_lane,                           \
+               static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3))
+    if (per_lane == 1) LAUNCH_GL(1);
+    else LAUNCH_GL(KARNEY_SERVICES);
+#undef LAUNCH_GL
     // the int64 digits and the residue read; every digit written as a residue of every limb (the call's output: 655 MB at M3A)
     MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * dpt + sizeof(W) + static_cast<double>(dpt) * L * sizeof(W)));
     MXX_LAUNCH(gauss_samp_expand_kernel<W>, item_grid(total, 256), dim3(256), 0,
@@ -618,7 +621,7 @@ __global__ void p1_divisor_kernel(KarneyDivisor *__restrict__ div, const double 
 // persistent-lane form for m <= 4 (rng.h): element = (column, coefficient), m dependent Karney
 // integers each (rows m-1 .. 0); integers go to the int64 staging array [row][col][N].  Keystream refills every
 // second checkpoint (fill_every; M3A: 0.47 -> 0.445 ms, every third 0.447)
-template <typename W, int MAXM>
+template <typename W, int MAXM, int SV>
 __global__ void __launch_bounds__(SAMPLER_THREADS) p1_sample_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ tp2,
                                        const double *__restrict__ sqrt_var_base, const double *__restrict__ update_base,
                                        const KarneyDivisor *__restrict__ div_base, uint32_t m, uint32_t cols, uint32_t L,
@@ -689,16 +692,16 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) p1_sample_lanes_kernel(int64_
         integer_ready();
         element_done();
         if (__all(f.st == KS_IDLE)) break;
-        rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0);
+        rng_fill_wave(rng, f.st != KS_IDLE, step % fill_every == 0, 16, karney_urgent(SV));
         karney_heavy(f, rng);
 #pragma unroll
-        for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
+        for (int s4 = 0; s4 < KARNEY_SUPERSTEP / SV; ++s4) karney_light(f, rng);
 #pragma unroll
-        for (int sv = 1; sv < KARNEY_SERVICES; ++sv) {
+        for (int sv = 1; sv < SV; ++sv) {
             integer_ready();
             karney_heavy(f, rng);
 #pragma unroll
-            for (int s4 = 0; s4 < KARNEY_LIGHTS; ++s4) karney_light(f, rng);
+            for (int s4 = 0; s4 < KARNEY_SUPERSTEP / SV; ++s4) karney_light(f, rng);
         }
     }
 }
@@ -835,13 +838,20 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
 #define LAUNCH_P1L(WT, MAXM)                                                                                      \
     do {                                                                                                          \
         const uint32_t per_lane =                                                                                 \
-            sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM>), ctx->device, ctx->env.sampler_per_lane); \
+            sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM, KARNEY_SERVICES>), ctx->device, ctx->env.sampler_per_lane); \
         const unsigned lblocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane)); \
-        MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM>), dim3(lblocks), dim3(SAMPLER_THREADS), 0, ctx->stream, \
-                           static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,    \
-                           cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m, \
-                           (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,           \
-                           static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2)); \
+        if (per_lane == 1)                                                                                        \
+            MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM, 1>), dim3(lblocks), dim3(SAMPLER_THREADS), 0, ctx->stream, \
+                       static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,        \
+                       cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m,   \
+                       (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,               \
+                       static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2));     \
+        else                                                                                                      \
+            MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM, KARNEY_SERVICES>), dim3(lblocks), dim3(SAMPLER_THREADS), 0, ctx->stream, \
+                       static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,        \
+                       cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m,   \
+                       (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,               \
+                       static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2));     \
     } while (0)
         if (ctx->wide) {
             if (m <= 2) LAUNCH_P1L(uint64_t, 2);
