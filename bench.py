@@ -1246,9 +1246,9 @@ def main():
                                    f"{64 ** 3 * N_RING * 8 * 5.0 / 64 / (SIMDS * CLOCK_GHZ * 1e9) * 1e3:.2f} ms")
         del m2b_wl
         if d.world == 1:
-            _, _, dec = sub_block("m2b_decompose", max(2, steps // 4), 2, cpu=False)
+            _, _, dec = sub_block("m2b_decompose", max(2, steps // 4), 2)
             m2b["decompose"] = dec
-            _, _, md = sub_block("m2b_mul_decompose", max(2, steps // 4), 2, cpu=False)
+            _, _, md = sub_block("m2b_mul_decompose", max(2, steps // 4), 2)
             m2b["mul_decompose"] = md
         line["m2b"] = m2b
         w3, r3, m3b = sub_block("m3b", steps, min(args.repeats, 3))
@@ -1280,8 +1280,7 @@ def main():
         elif d.world == 1 and not args.no_trace and not isinstance(wl, MatMul):
             line["roofline"] = composed_roofline(wl, res["kernel_ms"][0])
         if d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:  # an N = 1 leg: the other ranks would wait for it
-            base_name = {"m2b_decompose": None, "m2b_mul_decompose": None}.get(args.workload, args.workload)
-            line["cpu_baseline"] = cpu_baseline(base_name, args.cpu_seconds) if base_name else None
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
     if d.rank == 0:
         line.setdefault("cpu_baseline", None)
         emit(line)
@@ -1314,7 +1313,7 @@ def cpu_baseline(wl: str, budget_s: float):
     O.use_native_build()  # -O3 -march=native -fopenmp for this host, in a temp dir
     lib = O.lib()
     cores = host_cores()
-    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m3a": 10, "m3b": 8, "m4": 12}[wl]
+    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m2b_decompose": 8, "m2b_mul_decompose": 8, "m3a": 10, "m3b": 8, "m4": 12}[wl]
     n = 256 if wl == "m4" else N_RING
     moduli = O.gen_crt_basis(n, depth, 51 if wl == "m4" else 24)
     mod = np.asarray(moduli, dtype=np.uint64)
@@ -1339,6 +1338,8 @@ def cpu_baseline(wl: str, budget_s: float):
         units, unit, width = polys, "ring-ops/s", 3
         reps_all, reps_one = 9, 5
         sample = f"{polys} of 1024 polys, same step (NTT, *w, INTT), Shoup butterflies + Barrett product"
+    elif wl in ("m2b_decompose", "m2b_mul_decompose"):
+        return cpu_baseline_decompose(O, wl, n, moduli, cores, out)
     else:
         return cpu_baseline_preimage(O, wl, n, moduli, cores, budget_s, out)
     sec_all = np.zeros(reps_all * width, dtype=np.float64)
@@ -1355,6 +1356,41 @@ def cpu_baseline(wl: str, budget_s: float):
     if wl == "m1":
         per = sec_all.reshape(reps_all, width)
         out["phase_median_s"] = {"ntt": float(np.median(per[:, 0])), "mul": float(np.median(per[:, 1])), "intt": float(np.median(per[:, 2]))}
+    return out
+
+
+def cpu_baseline_decompose(O, wl, n, moduli, cores, out):
+    """G^-1 of a 2 x 2 block of the 64 x 64 matrix (inverse transform, digit extraction, forward transform of the 64 digit
+    polynomials) and, for mul_decompose, the product of an (8 x 32) block of S with them: the C / OpenMP kernels of the
+    restatement, Python only sequences them."""
+    import numpy as np
+
+    def timed(fn, reps, threads):
+        O.lib().orc_set_threads(threads)
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return np.asarray(ts)
+
+    m = O.matrix_ntt(O.random_matrix(11, 2, 2, moduli, n), moduli)
+    k = O.digits_per_tower(moduli, 12) * len(moduli)
+    dec = lambda: O.matrix_ntt(O.decompose(O.matrix_ntt(m, moduli, inverse=True), moduli, 12), moduli)
+    if wl == "m2b_decompose":
+        fn, units, unit = dec, 4, "ring-elements/s"
+        sample = "G^-1 of a 2 x 2 block of the 64 x 64 matrix (4 ring elements -> 64 digit polynomials in EVAL form)"
+    else:
+        s = O.matrix_ntt(O.random_matrix(12, 8, 2 * k, moduli, n), moduli)
+        fn, units, unit = (lambda: O.matmul(s, dec(), moduli, fast=True)), 8 * 2 * k * 2, "ring-ops/s"
+        sample = f"(8 x {2 * k}) * G^-1(2 x 2): a 2-column, 2-source-row block of the (8 x 1024) * G^-1(64 x 64) call"
+    t_all, t_one = timed(fn, 7, cores), timed(fn, 3, 1)
+    O.lib().orc_set_threads(cores)
+    out.update({"value": units / float(np.median(t_all)), "unit": unit, "median_s": float(np.median(t_all)), "min_s": float(t_all.min()),
+                "reps": 7, "one_core": {"value": units / float(np.median(t_one)), "cores": 1, "median_s": float(np.median(t_one)),
+                                        "min_s": float(t_one.min()), "reps": 3},
+                "sample": sample + "; median after a warm-up"})
     return out
 
 
