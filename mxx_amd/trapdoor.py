@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import threading
+import weakref
 
 from .matrix import GpuDCRTPolyMatrix
 from .sampler import DistType, GpuDCRTPolyUniformSampler, random_gpu_rng_seed
@@ -57,6 +58,7 @@ class GpuDCRTTrapdoor:
         self.d_mat_coeff = _coeff_cached(e * et)
         self._p1_cache = None
         self._p1_lock = threading.Lock()
+        self._stacked = None  # ([R; E; right], the public-matrix block it was built from): see stacked_left_factor
 
     @classmethod
     def new(cls, params, size: int, sigma: float) -> "GpuDCRTTrapdoor":
@@ -74,6 +76,21 @@ class GpuDCRTTrapdoor:
             )
             self._p1_cache = ((c, s, dgg_stddev), cache)
             return cache
+
+    def public_matrix_parts(self, public_matrix: GpuDCRTPolyMatrix):
+        """(left, right, [R; E; right]) of A = [left | right] for this trapdoor: the two column blocks the preimage multiplies
+        by p1 / p2 and the stacked left factor of the one product over p2 that yields both [R;E] p2 and right p2.  Built once
+        per public-matrix OBJECT (callers keep a trapdoor with its matrix: `src/sampler/trapdoor/gpu.rs:228-369` slices A on
+        every call) and reused while that object is alive; a caller that rewrites the matrix in place must pass a new one."""
+        with self._p1_lock:
+            if self._stacked is not None and self._stacked[0]() is public_matrix:
+                return self._stacked[1]
+            d, p1_rows, p2_rows = public_matrix.row_size(), self.re.row_size(), self.re.col_size()
+            left = public_matrix.slice(0, d, 0, p1_rows)
+            right = public_matrix.slice(0, d, p1_rows, p1_rows + p2_rows)
+            parts = (left, right, self.re.concat_rows([right]))
+            self._stacked = (weakref.ref(public_matrix), parts)
+            return parts
 
     def to_params(self, params) -> "GpuDCRTTrapdoor":
         """Replica of the trapdoor on another device context: two peer copies (R, E) and the small products
@@ -146,23 +163,31 @@ class GpuDCRTPolyTrapdoorSampler:
         a1 = g - (a_bar * td.r + td.e)
         return td, a0.concat_columns([a1])
 
-    def _sample_pert(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol, right=None):
-        """`sample_pert_square_mat_gpu_native_parts` (gpu.rs:423-474).  With `right` (the public matrix's columns over
-        p2) the product right * p2 the caller needs next rides in the same pass over p2 as [R;E] p2: one product with the
-        stacked left factor.  Returns p1, p2, [R;E] p2 (EVAL, kept for the final assembly) and right * p2 (or None)."""
+    def _sample_pert(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol):
+        """`sample_pert_square_mat_gpu_native_parts` (gpu.rs:423-474): (p1, p2), the reference's signature."""
+        return self._sample_pert_parts(params, td, s, c, dgg_stddev, sigma_large, total_ncol)[:2]
+
+    def _sample_pert_parts(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol, stacked=None):
+        """The same with the by-products the large-operand assembly reuses.  With `stacked` = [R; E; right] (right = the
+        public matrix's columns over p2; `GpuDCRTTrapdoor.public_matrix_parts`) the product right * p2 the caller needs next
+        rides in the same pass over p2 as [R;E] p2.  Returns p1, p2, [R;E] p2 (EVAL, kept for the final assembly) and
+        right * p2 (or None); the last two are row views of the one product - no copies - and only the p1 sampler, which
+        takes its argument to the coefficient domain in place, gets a slice of its own."""
         u = GpuDCRTPolyUniformSampler()
         d, dk = td.r.row_size(), td.r.col_size()
         padded = -(-total_ncol // d) * d
         p2 = u.sample_uniform(params, dk, padded, DistType.GaussDist(sigma_large))
-        rp2 = None
-        if right is not None and _traffic_bound(params, dk * padded):
-            t = td.re.concat_rows([right]) * p2
-            tp2 = t.slice(0, td.re.row_size(), 0, padded)
-            rp2 = t.slice(td.re.row_size(), t.row_size(), 0, padded)
+        rp2 = tp2_eval = None
+        if stacked is not None and _traffic_bound(params, dk * padded):
+            t = stacked * p2
+            re_rows = td.re.row_size()
+            tp2 = t.slice(0, re_rows, 0, padded)
+            tp2_eval = t.row_view(0, re_rows)
+            rp2 = t.row_view(re_rows, t.row_size())
         else:
             tp2 = td.re * p2
-        # the p1 sampler takes its argument to the coefficient domain in place
-        tp2_eval = tp2.clone() if _traffic_bound(params, dk * padded) else None
+            if _traffic_bound(params, dk * padded):
+                tp2_eval = tp2.clone()
         cache = td.p1_covariance_cache(c, s, dgg_stddev)
         p1 = GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2, random_gpu_rng_seed())
         return p1, p2, tp2_eval, rp2
@@ -177,9 +202,8 @@ class GpuDCRTPolyTrapdoorSampler:
         dgg_large_std = math.sqrt(s * s - self.c * self.c)
         p1_rows, p2_rows = td.re.row_size(), td.re.col_size()
         assert public_matrix.col_size() == p1_rows + p2_rows, "public matrix columns must match perturbation rows"
-        left = public_matrix.slice(0, d, 0, p1_rows)
-        right = public_matrix.slice(0, d, p1_rows, p1_rows + p2_rows)
-        p1, p2, tp2, rp2 = self._sample_pert(params, td, s, self.c, self.sigma, dgg_large_std, target_cols, right)
+        left, right, stacked = td.public_matrix_parts(public_matrix)
+        p1, p2, tp2, rp2 = self._sample_pert_parts(params, td, s, self.c, self.sigma, dgg_large_std, target_cols, stacked)
         assert (p1.row_size(), p2.row_size()) == (p1_rows, p2_rows)
         p_hat_image = (left * p1) + (rp2 if rp2 is not None else right * p2)
         if p_hat_image.col_size() != target_cols:

@@ -523,7 +523,7 @@ def test_gpu_p_hat_coefficients_below_compute_preimage_norm(gpu):
     s = preimage_smoothing_parameter(base, SIGMA, size, n, k)
     dgg_large_std = math.sqrt(s * s - c * c)
     for _sample in range(4):
-        p1, p2 = sampler._sample_pert(p, trapdoor, s, c, SIGMA, dgg_large_std, size)[:2]
+        p1, p2 = sampler._sample_pert(p, trapdoor, s, c, SIGMA, dgg_large_std, size)
         p_hat = p1.slice_columns(0, size).concat_rows([p2.slice_columns(0, size)])  # sample_pert_square_mat_gpu_native, :497-531
         assert _max_centred(p_hat) < bound
 
