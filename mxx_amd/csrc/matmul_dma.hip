@@ -210,16 +210,18 @@ __global__ void __launch_bounds__(512, 2)
         }
     }
     const BoundedReduce br = bounded_reduce_setup(lc.kbits, lc.mu64, inner);
+    // the output pointer is carried along the tile by two strides (see kernel_u32 of mmdma32 below)
+    const uint32_t c_first = c0 + wc * 8u;
+    uint32_t *const dst00 = C + (static_cast<size_t>(r0 + wr * 8u) * cols + c_first) * polyw + slot_base + lane;
+    const size_t row_step = static_cast<size_t>(cols) * polyw;
     auto store_tile = [&](auto reduce) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const uint32_t r = r0 + wr * 8 + i;
-            if (r >= rows) continue;
+            if (r0 + wr * 8 + i >= rows) continue;
+            uint32_t *dst = dst00 + i * row_step;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t c = c0 + wc * 8 + j;
-                if (c >= cols) continue;
-                uint32_t *dst = C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + lane;
+            for (int j = 0; j < 8; ++j, dst += polyw) {
+                if (c_first + j >= cols) continue;
                 if (nt_c) __builtin_nontemporal_store(reduce(acc[i][j]), dst);  // see kernel_u32 of mmdma32 below
                 else *dst = reduce(acc[i][j]);
             }
@@ -373,19 +375,23 @@ __global__ void __launch_bounds__(1024, 4)
         stage = (stage + 1) % STAGES;
     }
     const BoundedReduce br = bounded_reduce_setup(lc.kbits, lc.mu64, inner);
+    // Round 4: the epilogue is a sixth of this kernel's instructions at an inner dimension of 64 (32 outputs per lane after
+    // 64 MACs each); the output pointer is carried along the tile by two strides instead of being rebuilt from (r, c) with
+    // 64-bit multiplies per output (11 -> ~4 VALU instructions per store).
+    const uint32_t c_first = c0 + wq * 8u + half * 4u;
+    uint32_t *const dst00 = C + (static_cast<size_t>(r0 + wr * 8u) * cols + c_first) * polyw + slot_base + slot;
+    const size_t row_step = static_cast<size_t>(cols) * polyw;
     auto store_tile = [&](auto reduce) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const uint32_t r = r0 + wr * 8 + i;
-            if (r >= rows) continue;
+            if (r0 + wr * 8 + i >= rows) continue;
+            uint32_t *dst = dst00 + i * row_step;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = c0 + wq * 8u + half * 4u + j;
-                if (c >= cols) continue;
+            for (int j = 0; j < 4; ++j, dst += polyw) {
+                if (c_first + j >= cols) continue;
                 // non-temporal when C is far larger than the Infinity Cache (nt_c, set by the launcher from 1 GiB): it is
                 // written once and must not displace the A / B panels their second reader still needs (-2..4 %); a small C
                 // stays cacheable for whatever reads it next
-                uint32_t *dst = C + (static_cast<size_t>(r) * cols + c) * polyw + slot_base + slot;
                 if (nt_c) __builtin_nontemporal_store(reduce(acc[i][j]), dst);
                 else *dst = reduce(acc[i][j]);
             }
