@@ -984,10 +984,14 @@ def exchange_report(mx, wls, ranks_seen, backend, devices):
         peer = _ffi.peer_access_matrix(sorted(set(devices)))
     except Exception as e:  # noqa: BLE001 - a report, not a gate
         peer = f"unavailable: {e}"
+    ok = all(c is not None for c in checked)
+    distinct = len(set(devices)) == len(devices)
     return {"ranks_seen": ranks_seen, "comm_backend": backend, "devices": devices, "peer_access": peer,
-            "foreign_blocks_checked_per_rank": checked,
-            "self_validated": all(c is not None for c in checked),
-            "distinct_devices": len(set(devices)) == len(devices)}
+            "foreign_blocks_checked_per_rank": checked, "self_validated": ok, "distinct_devices": distinct,
+            # no multi-device run of this exchange exists in the repo's history (the pool hands out one GPU per
+            # box); a line with distinct devices and self_validated = true is the first evidence, and carries it itself
+            "comm_verified_on_distinct_devices_before_this_run": False,
+            "comm_verified_by_this_run": bool(ok and distinct and len(devices) > 1)}
 
 
 def torch_exchange_report(wl, d):
@@ -1002,10 +1006,13 @@ def torch_exchange_report(wl, d):
     except Exception as e:  # noqa: BLE001
         peer = f"unavailable: {e}"
     checked = [e["foreign_blocks_checked"] for e in everyone]
+    ok = all(c is not None for c in checked)
+    distinct = len(set(devices)) == len(devices)
     return {"ranks_seen": d.dist.get_world_size(), "comm_backend": f"torch.distributed '{d.backend}'" + (" (RCCL)" if d.backend == "nccl" else " (rehearsal, not xGMI)"),
             "devices": devices, "peer_access": peer, "foreign_blocks_checked_per_rank": checked,
-            "self_validated": all(c is not None for c in checked),
-            "distinct_devices": len(set(devices)) == len(devices)}
+            "self_validated": ok, "distinct_devices": distinct,
+            "comm_verified_on_distinct_devices_before_this_run": False,
+            "comm_verified_by_this_run": bool(ok and distinct and len(devices) > 1 and d.backend == "nccl")}
 
 
 def run_block_inproc(mx, wls, comm, steps, warmup, repeats):
