@@ -59,3 +59,15 @@ for name, n, depth, bits in (("samplers_n16_d3_b18", 16, 3, 18), ("samplers_n8_d
         out[dist + "_window"] = O.sample_distribution(2, 2, moduli, n, dist, sigma, SEED, full_ncol=3, col_offset=1)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name)
+
+# the same samplers under the REFERENCE device RNG's own keying (round 4: MXX_HIP_RNG_COMPAT=reference; restated from
+# cuda/src/ChaCha.cu:104-167 + cuda/src/matrix/MatrixSampling.cu:239-289 in oracle/oracle_sampling.c): a fixture a CUDA build
+# of the reference could be checked against, should one ever be run next to this library
+for name, n, depth, bits in (("samplers_refkey_n16_d3_b18", 16, 3, 18), ("samplers_refkey_n8_d2_b51", 8, 2, 51)):
+    moduli = O.gen_crt_basis(n, depth, bits)
+    out = {"moduli": np.asarray(moduli, dtype=np.uint64), "n": n, "seed": np.frombuffer(SEED, dtype=np.uint8)}
+    for dist, sigma in (("uniform", 0.0), ("bit", 0.0), ("ternary", 0.0), ("gauss", 4.578)):
+        out[dist] = O.sample_distribution_refkey(2, 3, moduli, n, dist, sigma, SEED)
+        out[dist + "_window"] = O.sample_distribution_refkey(2, 2, moduli, n, dist, sigma, SEED, full_ncol=3, col_offset=1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)

@@ -25,13 +25,18 @@ def seed(gpu, salt=0):
     return gpu.GpuRngSeed.from_bytes(bytes(b))
 
 
-def test_sampler_golden_fixtures_on_gpu(gpu, oracle):
+def test_sampler_golden_fixtures_on_gpu(gpu, oracle, hip_env):
     """The committed sampler fixtures (tests/golden/samplers_*.npz) against the device: every distribution, the full
     matrix and its column window."""
     import os
 
     gdir = os.path.join(os.path.dirname(__file__), "golden")
     for f in sorted(x for x in os.listdir(gdir) if x.startswith("samplers_")):
+        # samplers_refkey_*: the same calls under MXX_HIP_RNG_COMPAT=reference (the reference device RNG's own keying)
+        if f.startswith("samplers_refkey_"):
+            hip_env.set("MXX_HIP_RNG_COMPAT", "reference")
+        else:
+            hip_env.unset("MXX_HIP_RNG_COMPAT")
         z = np.load(os.path.join(gdir, f))
         moduli, n = [int(q) for q in z["moduli"]], int(z["n"])
         p = gpu.GpuDCRTPolyParams(n, moduli, 6)
