@@ -256,6 +256,7 @@ int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t
 int launch_ntt_digits_u64(GpuContext *ctx, uint64_t *out, const uint64_t *coeff, size_t out_vectors, uint32_t L,
                           uint32_t src_cols, uint32_t towers, uint32_t dpt, uint32_t base_bits, size_t k);
 // out <- INTT(in o w), w one resident EVAL-form ring element [L][N]; -1: no fused kernel for this context
+int launch_intt_oop_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, size_t vectors, uint32_t L);
 int launch_ntt_add_u32(GpuContext *ctx, uint32_t *out, const uint32_t *src, const uint32_t *add, size_t vectors, uint32_t L);
 int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, const uint32_t *w, size_t vectors, uint32_t L);
 int launch_matmul(GpuMatrix *out, const GpuMatrix *lhs, const GpuMatrix *rhs);

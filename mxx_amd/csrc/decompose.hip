@@ -146,8 +146,13 @@ static int decompose_impl(const GpuMatrix *src, uint32_t base_bits, GpuMatrix *o
     CtxBlock tmp_block(ctx);  // back to the cache at scope exit (stream-ordered behind its readers), error paths included
     if (src->format == GPU_POLY_FORMAT_EVAL) {
         if (tmp_block.alloc(src->bytes)) return 1;
-        HIP_TRY(hipMemcpyAsync(tmp_block.ptr, src->data, src->bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        int rc = launch_ntt(ctx, tmp_block.ptr, polys * L, static_cast<int>(L), true);
+        int rc = ctx->wide ? -1 : launch_intt_oop_u32(ctx, static_cast<uint32_t *>(tmp_block.ptr), static_cast<const uint32_t *>(src->data),
+                                                      polys * L, static_cast<uint32_t>(L));
+        if (rc < 0) {  // no out-of-place transform for this context: copy, then in place
+            MXX_TRACED_COPY("copy (device to device)", ctx->stream, 2.0 * src->bytes,
+                            HIP_TRY(hipMemcpyAsync(tmp_block.ptr, src->data, src->bytes, hipMemcpyDeviceToDevice, ctx->stream)));
+            rc = launch_ntt(ctx, tmp_block.ptr, polys * L, static_cast<int>(L), true);
+        }
         if (rc) return rc;
         coeff = tmp_block.ptr;
     }

@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(512, WPS / (sizeof(W) / 4))
     const W muw = static_cast<W>(sizeof(W) == 4 ? lc.mu32 : lc.mu64);
     const TwPair<W> *tw = tw_all + static_cast<size_t>(limb) * N;
     W *g = data + vec * N;
+    const W *gin = (!MULW && in) ? in + vec * N : g;  // out of place without MULW: `in` must not overlap `data`
 
     // MULW: operands of the group after the current one, requested a group ahead
     V16 dnext[8 / VN], wnext[8 / VN];
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(512, WPS / (sizeof(W) / 4))
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = csub<W>(mont_mul_lazy(v[m], wv[m], q, qninv), q);  // canonical, as a load would give
             } else {
-                const W *src = g + B * BLK + 8 * lane;
+                const W *src = gin + B * BLK + 8 * lane;
 #pragma unroll
                 for (int m = 0; m < 8; m += VN) nt_load16<NT, W>(&v[m], src + m);
             }

@@ -16,6 +16,19 @@ int launch_mul_intt_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, cons
     return launch_mul_intt(ctx, out, in, w, vectors, L);
 }
 
+// out = INTT(in), `in` left untouched (ntt14.h, inv_kernel reading from `in`): the decompose paths need the coefficients
+// of an EVAL source that must stay EVAL - a device copy followed by the in-place transform moves the matrix three
+// times, this moves it twice.  -1: the grouped 2^14 kernel does not run for this context / path override, the caller
+// then copies and transforms in place.
+int launch_intt_oop_u32(GpuContext *ctx, uint32_t *out, const uint32_t *in, size_t vectors, uint32_t L) {
+    const EnvSwitches &env = ctx->env;
+    if (ctx->logN != 14 || !(ctx->lazy_ok || ctx->tight_ok) || env.ntt14 == 1 || env.ntt_path > 1) return -1;
+    dim3 grid;
+    if (vectors == 0 || vectors > 0x7fffffffull || !ntt14_grid(vectors, L, grid)) return -1;
+    MXX_TRACE_BYTES(2.0 * vectors * ntt14::N * sizeof(W));
+    return ctx->lazy_ok ? launch_ntt14<false>(ctx, out, vectors, L, true, in) : launch_ntt14<true>(ctx, out, vectors, L, true, in);
+}
+
 // out = NTT(src) + add in one pass (ntt14.h, fwd_add_kernel); -1: no fused kernel for this context / path override,
 // the caller then copies, transforms in place and adds
 int launch_ntt_add_u32(GpuContext *ctx, uint32_t *out, const uint32_t *src, const uint32_t *add, size_t vectors, uint32_t L) {

@@ -677,14 +677,17 @@ class GpuDCRTPolyMatrix:
         return out
 
     def decompose(self) -> "GpuDCRTPolyMatrix":
-        return self.clone().decompose_owned()
+        # an EVAL source goes to the library as it is: its coefficients are produced by an out-of-place inverse
+        # transform into a scratch block (decompose.hip), not by clone() + in-place INTT (gpu_dcrt_poly.rs:1227-1233)
+        return self._decompose_from(self, self.nrow * self.params.modulus_digits(), False)
 
     def decompose_owned(self) -> "GpuDCRTPolyMatrix":
         self.intt_all_in_place()
         return self._decompose_from(self, self.nrow * self.params.modulus_digits(), False)
 
     def small_decompose(self) -> "GpuDCRTPolyMatrix":
-        return self.clone().small_decompose_owned()
+        k = -(-self.params.crt_bits() // self.params.base_bits())
+        return self._decompose_from(self, self.nrow * k, True)
 
     def small_decompose_owned(self) -> "GpuDCRTPolyMatrix":
         self.intt_all_in_place()
