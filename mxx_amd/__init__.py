@@ -17,7 +17,16 @@ from ._ffi import (  # noqa: F401
     detected_gpu_device_ids,
     gpu_device_sync,
 )
-from .matrix import GpuDCRTPolyMatrix, GpuP1CovarianceCache  # noqa: F401
+from .matrix import (  # noqa: F401
+    GpuDCRTMatrixRnsSnapshot,
+    GpuDCRTPolyMatrix,
+    GpuP1CovarianceCache,
+    block_offsets,
+    block_size,
+    one_rns_bytes,
+    rns_bytes_len,
+    rns_bytes_len_for_level,
+)
 from .params import DCRTPolyParams, GpuContext, GpuDCRTPolyParams, gen_crt_basis  # noqa: F401
 from .poly import GpuDCRTPoly  # noqa: F401
 from .sampler import (  # noqa: F401

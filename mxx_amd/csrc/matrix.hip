@@ -537,14 +537,15 @@ extern "C" int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_o
     if (bytes_per_poly % 8 != 0 || bytes_per_poly < wpp * 8)
         return set_error("gpu_matrix_store_rns_batch: bytes_per_poly must be a multiple of 8 and >= (level+1)*N*8");
     if (ctx_activate(ctx)) return 1;
-    size_t dst_wpp = bytes_per_poly / 8;
+    // staged tightly; a padded stride goes out as a 2-D copy that leaves the host's padding bytes untouched, as the
+    // reference's cudaMemcpy2DAsync does (MatrixSerde.cu:895-903)
+    const size_t tight = wpp * 8;
     const size_t max_stage_bytes = size_t(512) << 20;
-    size_t polys_per_chunk = std::max<size_t>(1, max_stage_bytes / bytes_per_poly);
+    size_t polys_per_chunk = std::max<size_t>(1, max_stage_bytes / tight);
     polys_per_chunk = std::min(polys_per_chunk, polys);
     CtxBlock stage_block(ctx);  // back to the cache at scope exit, error paths included
-    if (stage_block.alloc(polys_per_chunk * bytes_per_poly)) return 1;
+    if (stage_block.alloc(polys_per_chunk * tight)) return 1;
     void *const stage = stage_block.ptr;
-    if (dst_wpp != wpp) HIP_TRY(hipMemsetAsync(stage, 0, polys_per_chunk * bytes_per_poly, ctx->stream));
     for (size_t p0 = 0; p0 < polys; p0 += polys_per_chunk) {
         size_t pc = std::min(polys_per_chunk, polys - p0);
         size_t total = pc * wpp;
@@ -552,14 +553,17 @@ extern "C" int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_o
         if (ctx->wide)
             MXX_LAUNCH(pack_rns_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                                static_cast<const uint64_t *>(mat->data) + p0 * wpp, static_cast<uint64_t *>(stage), wpp,
-                               dst_wpp, total);
+                               wpp, total);
         else
             MXX_LAUNCH(pack_rns_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                                static_cast<const uint32_t *>(mat->data) + p0 * wpp, static_cast<uint64_t *>(stage), wpp,
-                               dst_wpp, total);
+                               wpp, total);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(bytes_out + p0 * bytes_per_poly, stage, pc * bytes_per_poly, hipMemcpyDeviceToHost,
-                               ctx->stream));
+        if (bytes_per_poly == tight)
+            HIP_TRY(hipMemcpyAsync(bytes_out + p0 * bytes_per_poly, stage, pc * tight, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(bytes_out + p0 * bytes_per_poly, bytes_per_poly, stage, tight, tight, pc,
+                                     hipMemcpyDeviceToHost, ctx->stream));
     }
     return make_event_set(ctx, out_events);  // stage_block returns to the cache here, stream-ordered after its readers
     ABI_GUARD_END
@@ -579,22 +583,24 @@ extern "C" int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t
         return set_error("gpu_matrix_store_const_coeff_batch requires Coeff format");
     if (words_per_poly < L) return set_error("gpu_matrix_store_const_coeff_batch: words_per_poly < limb count");
     if (ctx_activate(ctx)) return 1;
-    size_t bytes = polys * words_per_poly * 8;
+    // staged as L words per polynomial; a wider stride is a 2-D copy that leaves the words beyond L untouched
+    // (MatrixSerde.cu:1041-1049)
+    size_t bytes = polys * L * 8;
     CtxBlock stage_block(ctx);
     if (stage_block.alloc(bytes)) return 1;
     void *const stage = stage_block.ptr;
-    if (words_per_poly != L) HIP_TRY(hipMemsetAsync(stage, 0, bytes, ctx->stream));
     const dim3 blocks = item_grid(polys * L, 256);
     if (ctx->wide)
         MXX_LAUNCH(const_coeff_kernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<const uint64_t *>(mat->data), static_cast<uint64_t *>(stage), polys, L,
-                           (size_t)ctx->N, words_per_poly);
+                           (size_t)ctx->N, L);
     else
         MXX_LAUNCH(const_coeff_kernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
                            static_cast<const uint32_t *>(mat->data), static_cast<uint64_t *>(stage), polys, L,
-                           (size_t)ctx->N, words_per_poly);
+                           (size_t)ctx->N, L);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(words_out, stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (words_per_poly == L) HIP_TRY(hipMemcpyAsync(words_out, stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    else HIP_TRY(hipMemcpy2DAsync(words_out, words_per_poly * 8, stage, L * 8, L * 8, polys, hipMemcpyDeviceToHost, ctx->stream));
     return make_event_set(ctx, out_events);  // stage_block returns to the cache here, stream-ordered after its readers
     ABI_GUARD_END
 }

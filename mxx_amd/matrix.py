@@ -51,6 +51,114 @@ def _bincode_read_varint(data: bytes, pos: int):
     return int.from_bytes(data[pos + 1 : pos + 1 + width], "little"), pos + 1 + width
 
 
+def block_size() -> int:
+    """`BLOCK_SIZE`, default 100 (src/env.rs:175-178): entries per side of a stored matrix block."""
+    try:
+        return int(os.environ.get("BLOCK_SIZE", "100"))
+    except ValueError:
+        return 100
+
+
+def block_offsets(rng: range, block: int) -> list:
+    """[start, start + block, ..., stop] (gpu_dcrt_poly.rs:1899-1909)."""
+    offsets, cur = [rng.start], rng.start
+    while cur < rng.stop:
+        cur = min(cur + block, rng.stop)
+        offsets.append(cur)
+    return offsets
+
+
+def rns_bytes_len_for_level(params, level: int) -> int:
+    """(level + 1) * n * 8: one polynomial in the `[limb][n]` u64 wire layout (gpu_dcrt_poly.rs:1916-1920)."""
+    assert level < params.crt_depth(), "invalid RNS byte length level"
+    return (level + 1) * params.ring_dimension() * 8
+
+
+def rns_bytes_len(params) -> int:
+    """gpu_dcrt_poly.rs:1911-1914."""
+    return rns_bytes_len_for_level(params, max(params.crt_depth() - 1, 0))
+
+
+def one_rns_bytes(params) -> bytes:
+    """EVAL wire bytes of the constant polynomial 1 (gpu_dcrt_poly.rs:1922-1932)."""
+    if rns_bytes_len(params) == 0:
+        return b""
+    one = GpuDCRTPolyMatrix.identity(params, 1)
+    return one.to_rns().tobytes()
+
+
+class GpuDCRTMatrixRnsSnapshot:
+    """Host copy of a matrix in the u64 wire layout with its shape, level and format tag
+    (gpu_dcrt_poly.rs:72-120): what callers keep between devices / across a device reset."""
+
+    __slots__ = ("_nrow", "_ncol", "_level", "_is_ntt", "_bytes_per_poly", "_bytes")
+
+    def __init__(self, nrow, ncol, level, is_ntt, bytes_per_poly, data):
+        self._nrow, self._ncol, self._level, self._is_ntt = int(nrow), int(ncol), int(level), bool(is_ntt)
+        self._bytes_per_poly = int(bytes_per_poly)
+        self._bytes = bytes(data)
+
+    def nrow(self) -> int:
+        return self._nrow
+
+    def ncol(self) -> int:
+        return self._ncol
+
+    def level(self) -> int:
+        return self._level
+
+    def is_ntt(self) -> bool:
+        return self._is_ntt
+
+    def bytes_per_poly(self) -> int:
+        return self._bytes_per_poly
+
+    def bytes(self) -> bytes:
+        return self._bytes
+
+    def validate_for_params(self, params) -> None:
+        assert self._level < params.crt_depth(), "invalid RNS snapshot level"
+        assert self._bytes_per_poly == rns_bytes_len_for_level(params, self._level), "RNS snapshot bytes_per_poly mismatch"
+        assert len(self._bytes) == self._nrow * self._ncol * self._bytes_per_poly, "RNS snapshot byte length mismatch"
+
+    def __eq__(self, other) -> bool:
+        if not isinstance(other, GpuDCRTMatrixRnsSnapshot):
+            return NotImplemented
+        return all(getattr(self, f) == getattr(other, f) for f in self.__slots__)
+
+    def __repr__(self) -> str:
+        return (f"GpuDCRTMatrixRnsSnapshot(nrow={self._nrow}, ncol={self._ncol}, level={self._level}, "
+                f"is_ntt={self._is_ntt}, bytes_per_poly={self._bytes_per_poly}, bytes={len(self._bytes)})")
+
+
+def _bincode_read_nested_bytes(data: bytes) -> list:
+    """bincode 2 `config::standard()` Vec<Vec<Vec<u8>>>: varint lengths, raw bytes innermost."""
+    pos = 0
+    nrows, pos = _bincode_read_varint(data, pos)
+    out = []
+    for _ in range(nrows):
+        ncols, pos = _bincode_read_varint(data, pos)
+        row = []
+        for _ in range(ncols):
+            blen, pos = _bincode_read_varint(data, pos)
+            assert pos + blen <= len(data), "truncated matrix block file"
+            row.append(data[pos : pos + blen])
+            pos += blen
+        out.append(row)
+    return out
+
+
+def _bincode_nested_bytes(entries) -> bytes:
+    """inverse of `_bincode_read_nested_bytes` (what the reference's `write_to_files` side produces)."""
+    parts = [_bincode_varint(len(entries))]
+    for row in entries:
+        parts.append(_bincode_varint(len(row)))
+        for e in row:
+            parts.append(_bincode_varint(len(e)))
+            parts.append(bytes(e))
+    return b"".join(parts)
+
+
 class GpuP1CovarianceCache:
     def __init__(self, raw, params=None):
         self.raw = raw
@@ -86,6 +194,8 @@ class GpuDCRTPolyMatrix:
     @classmethod
     def zero(cls, params, nrow, ncol) -> "GpuDCRTPolyMatrix":
         return cls._new_zero_with_state(params, nrow, ncol, params.crt_depth() - 1, True)
+
+    new_zero = zero  # gpu_dcrt_poly.rs:367-370
 
     @classmethod
     def _new_zero_with_state(cls, params, nrow, ncol, level, is_ntt) -> "GpuDCRTPolyMatrix":
@@ -175,6 +285,100 @@ class GpuDCRTPolyMatrix:
         st = _ffi.lib().gpu_matrix_store_rns_batch(self.raw, out.ctypes.data, self._bytes_per_poly(), fmt, C.byref(events))
         check_status(st, "gpu_matrix_store_rns_batch")
         _ffi.wait_and_destroy_events(events)
+        return out
+
+    # ---- the reference's byte-slice forms of the same transfers (gpu_dcrt_poly.rs:576-596,629-711) ----------------
+    def bytes_per_poly(self) -> int:
+        return self._bytes_per_poly()
+
+    def load_rns_bytes(self, data, bytes_per_poly: int, fmt: int) -> None:
+        """`load_rns_bytes(bytes, bytes_per_poly, format)`: polynomials `bytes_per_poly` apart, retagged to `fmt`."""
+        if len(data) == 0 or bytes_per_poly == 0:
+            return
+        buf = np.frombuffer(data, dtype=np.uint8)
+        assert len(buf) >= self.nrow * self.ncol * bytes_per_poly, "load_rns_bytes: buffer too small"
+        events = C.c_void_p()
+        st = _ffi.lib().gpu_matrix_load_rns_batch(self.raw, buf.ctypes.data, bytes_per_poly, fmt, C.byref(events))
+        check_status(
+            st,
+            f"gpu_matrix_load_rns_batch(nrow={self.nrow}, ncol={self.ncol}, level={self.level}, current_ntt={self.is_ntt}, "
+            f"format={fmt}, bytes={len(buf)}, bytes_per_poly={bytes_per_poly}, ring_dim={self.params.ring_dimension()}, "
+            f"crt_depth={self.params.crt_depth()})",
+        )
+        _ffi.wait_and_destroy_events(events)
+        self.is_ntt = fmt == GPU_POLY_FORMAT_EVAL
+
+    def store_rns_bytes(self, bytes_out, bytes_per_poly: int, fmt: int) -> None:
+        """`store_rns_bytes(bytes_out, bytes_per_poly, format)` into a writable buffer (bytearray / numpy uint8);
+        `fmt` must be the matrix's current format (the library refuses a conversion, MatrixSerde.cu:765-768)."""
+        if len(bytes_out) == 0 or bytes_per_poly == 0:
+            return
+        buf = np.frombuffer(bytes_out, dtype=np.uint8)
+        assert buf.flags.writeable, "store_rns_bytes needs a writable buffer"
+        assert len(buf) >= self.nrow * self.ncol * bytes_per_poly, "store_rns_bytes: buffer too small"
+        events = C.c_void_p()
+        st = _ffi.lib().gpu_matrix_store_rns_batch(self.raw, buf.ctypes.data, bytes_per_poly, fmt, C.byref(events))
+        check_status(st, "gpu_matrix_store_rns_batch")
+        _ffi.wait_and_destroy_events(events)
+
+    def to_rns_snapshot(self) -> "GpuDCRTMatrixRnsSnapshot":
+        bpp = rns_bytes_len_for_level(self.params, self.level)
+        data = bytearray(self.nrow * self.ncol * bpp)
+        self.store_rns_bytes(data, bpp, GPU_POLY_FORMAT_EVAL if self.is_ntt else GPU_POLY_FORMAT_COEFF)
+        return GpuDCRTMatrixRnsSnapshot(self.nrow, self.ncol, self.level, self.is_ntt, bpp, data)
+
+    @classmethod
+    def from_rns_snapshot(cls, params, snapshot: "GpuDCRTMatrixRnsSnapshot") -> "GpuDCRTPolyMatrix":
+        snapshot.validate_for_params(params)
+        out = cls(params, snapshot.nrow(), snapshot.ncol(), snapshot.level(), snapshot.is_ntt())
+        if snapshot.bytes():
+            out.load_rns_bytes(snapshot.bytes(), snapshot.bytes_per_poly(),
+                               GPU_POLY_FORMAT_EVAL if snapshot.is_ntt() else GPU_POLY_FORMAT_COEFF)
+        return out
+
+    def load_rns_snapshot(self, snapshot: "GpuDCRTMatrixRnsSnapshot") -> None:
+        snapshot.validate_for_params(self.params)
+        assert self.nrow == snapshot.nrow(), "RNS snapshot row count mismatch"
+        assert self.ncol == snapshot.ncol(), "RNS snapshot column count mismatch"
+        assert self.level == snapshot.level(), "RNS snapshot level mismatch"
+        assert self.is_ntt == snapshot.is_ntt(), "RNS snapshot format mismatch"
+        if not snapshot.bytes():
+            return
+        self.load_rns_bytes(snapshot.bytes(), snapshot.bytes_per_poly(),
+                            GPU_POLY_FORMAT_EVAL if snapshot.is_ntt() else GPU_POLY_FORMAT_COEFF)
+
+    def to_cpu_matrix(self) -> np.ndarray:
+        """`to_cpu_matrix` (gpu_dcrt_poly.rs:722-767): the CPU side receives EVAL residues, (rows, cols, L, n) u64."""
+        return self.to_eval_rns()
+
+    @classmethod
+    def read_from_files(cls, params, nrow: int, ncol: int, dir_path, ident: str) -> "GpuDCRTPolyMatrix":
+        """`read_from_files` (gpu_dcrt_poly.rs:1594-1641): blocks of `BLOCK_SIZE` x `BLOCK_SIZE` entries, one file
+        `{id}_{bsize}_{r0}.{r1}_{c0}.{c1}.matrix` each, holding bincode(Vec<Vec<Vec<u8>>>) of EVAL wire bytes per entry;
+        short or missing entries are zero-padded, as there."""
+        bsize = min(block_size(), max(nrow, 1), max(ncol, 1))
+        out = cls.new_empty(params, nrow, ncol)
+        bpp = rns_bytes_len(params)
+        rows_off, cols_off = block_offsets(range(0, nrow), bsize), block_offsets(range(0, ncol), bsize)
+        for r0, r1 in zip(rows_off, rows_off[1:]):
+            for c0, c1 in zip(cols_off, cols_off[1:]):
+                path = os.path.join(os.fspath(dir_path), f"{ident}_{bsize}_{r0}.{r1}_{c0}.{c1}.matrix")
+                try:
+                    with open(path, "rb") as fh:
+                        entries = _bincode_read_nested_bytes(fh.read())
+                except OSError as e:
+                    raise RuntimeError(f"Failed to read matrix file {path!r}") from e
+                rl, cl = r1 - r0, c1 - c0
+                flat = bytearray(rl * cl * bpp)
+                for i in range(rl):
+                    for j in range(cl):
+                        if i < len(entries) and j < len(entries[i]):
+                            src = entries[i][j][:bpp]
+                            start = (i * cl + j) * bpp
+                            flat[start : start + len(src)] = src
+                block = cls.new_empty(params, rl, cl)
+                block.load_rns_bytes(flat, bpp, GPU_POLY_FORMAT_EVAL)
+                out.copy_block_from(block, r0, c0, 0, 0, rl, cl)
         return out
 
     def to_coeff_rns(self) -> np.ndarray:
@@ -339,6 +543,8 @@ class GpuDCRTPolyMatrix:
                 raw,
             ]
         )
+
+    into_cpu_staging_bytes = to_cpu_staging_bytes  # the consuming form (gpu_dcrt_poly.rs:1046)
 
     @classmethod
     def from_cpu_staging_bytes(cls, params, data: bytes) -> "GpuDCRTPolyMatrix":

@@ -85,9 +85,44 @@ class GpuDCRTPoly:
         n = params.ring_dimension()
         return cls.from_biguints(params, [(value >> i) & 1 for i in range(n)])
 
+    @classmethod
+    def from_u64_vecs(cls, params, coeffs) -> "GpuDCRTPoly":
+        """coeffs[i] = the residues of coefficient i, limb by limb (gpu.rs:758-788): the limb count of the longest entry
+        sets the level, missing residues are 0, the polynomial stays in COEFF form."""
+        n = params.ring_dimension()
+        assert len(coeffs) <= n, f"coeffs length must be <= ring dimension (got {len(coeffs)}, expected <= {n})"
+        num_limbs = max([len(v) for v in coeffs] + [1])
+        assert num_limbs <= params.crt_depth(), "coeff limb count exceeds CRT depth"
+        flat = np.zeros((num_limbs, n), dtype=np.uint64)
+        for i, c in enumerate(coeffs):
+            flat[: len(c), i] = c
+        return cls._from_residues(params, flat, False)
+
+    @classmethod
+    def from_inner(cls, inner: GpuDCRTPolyMatrix) -> "GpuDCRTPoly":
+        return cls(inner)
+
     # ---- accessors -----------------------------------------------------------------
     def params(self) -> GpuDCRTPolyParams:
         return self.inner.params
+
+    params_ref = params
+
+    def level(self) -> int:
+        return self.inner.level
+
+    def ntt_in_place(self) -> None:
+        self.inner.ntt_all_in_place()
+
+    def store_rns_bytes(self, bytes_out, fmt: int) -> None:
+        """gpu.rs:790-795: the whole buffer is one polynomial's stride."""
+        if len(bytes_out) == 0:
+            return
+        self.inner.store_rns_bytes(bytes_out, len(bytes_out), fmt)
+
+    def assert_compatible(self, other: "GpuDCRTPoly") -> None:
+        assert self.level() == other.level(), "GPU polynomials must have the same level"
+        assert self.params() == other.params(), "GPU params must match"
 
     def is_ntt(self) -> bool:
         return self.inner.is_ntt

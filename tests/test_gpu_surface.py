@@ -587,3 +587,129 @@ def test_gate_batch_all_kinds_against_the_oracle(gpu, oracle, n, depth, bits, ba
     ops[0].kind, ops[0].out, ops[0].lhs, ops[0].rhs = _ffi.GPUPOLY_OP_ADD, outs[0].raw, outs[1].raw, outs[1].raw
     ops[1].kind, ops[1].out, ops[1].lhs, ops[1].rhs = _ffi.GPUPOLY_OP_ADD, outs[1].raw, outs[1].raw, outs[1].raw
     assert _ffi.lib().gpupoly_batch(ops, 2, base) != 0 and "aliases" in _ffi.last_error_string()
+
+
+# ---- RNS snapshots, byte-slice transfers, stored matrix blocks (gpu_dcrt_poly.rs:72-120,576-711,1594-1641) ----------
+def _snap_params(gpu):
+    from mxx_amd.params import DCRTPolyParams
+
+    moduli, _b, _d = DCRTPolyParams(256, 3, 20, 5).to_crt()
+    return gpu.GpuDCRTPolyParams(256, moduli, 5)
+
+
+def test_rns_snapshot_round_trip_and_validation(gpu):
+    p = _snap_params(gpu)
+    seed = gpu.GpuRngSeed.from_bytes(bytes(range(32)))
+    for is_ntt in (True, False):
+        m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 3, 2, gpu.GPU_MATRIX_DIST_UNIFORM, 0.0, seed)
+        if not is_ntt:
+            m = m.into_coeff_domain()
+        snap = m.to_rns_snapshot()
+        assert (snap.nrow(), snap.ncol(), snap.level(), snap.is_ntt()) == (3, 2, 2, is_ntt)
+        assert snap.bytes_per_poly() == gpu.rns_bytes_len_for_level(p, 2) == 3 * 256 * 8 == gpu.rns_bytes_len(p)
+        assert snap.bytes() == m.to_rns().tobytes()  # the numpy form of the same wire layout
+        back = gpu.GpuDCRTPolyMatrix.from_rns_snapshot(p, snap)
+        assert back.is_ntt == is_ntt and back == m
+        assert back.to_rns_snapshot() == snap
+        other = gpu.GpuDCRTPolyMatrix.zero(p, 3, 2) if is_ntt else gpu.GpuDCRTPolyMatrix.zero(p, 3, 2).into_coeff_domain()
+        other.load_rns_snapshot(snap)
+        assert other == m
+    wrong_shape = gpu.GpuDCRTPolyMatrix.zero(p, 2, 3)
+    with pytest.raises(AssertionError, match="row count mismatch"):
+        wrong_shape.load_rns_snapshot(snap)
+    wrong_format = gpu.GpuDCRTPolyMatrix.zero(p, 3, 2)  # EVAL, the last snapshot is COEFF
+    with pytest.raises(AssertionError, match="format mismatch"):
+        wrong_format.load_rns_snapshot(snap)
+    bad = gpu.GpuDCRTMatrixRnsSnapshot(3, 2, 2, True, snap.bytes_per_poly(), snap.bytes()[:-8])
+    with pytest.raises(AssertionError, match="byte length mismatch"):
+        gpu.GpuDCRTPolyMatrix.from_rns_snapshot(p, bad)
+    with pytest.raises(AssertionError, match="invalid RNS snapshot level"):
+        gpu.GpuDCRTMatrixRnsSnapshot(1, 1, 3, True, 4 * 256 * 8, bytes(4 * 256 * 8)).validate_for_params(p)
+    empty = gpu.GpuDCRTPolyMatrix.new_empty(p, 0, 4).to_rns_snapshot()
+    assert empty.bytes() == b"" and gpu.GpuDCRTPolyMatrix.from_rns_snapshot(p, empty).size() == (0, 4)
+
+
+def test_rns_bytes_with_a_padded_stride(gpu):
+    """bytes_per_poly may exceed (level + 1) n 8 (a multiple of 8): the padding is skipped on load and left untouched on
+    store; a store in the other format is refused with the reference's message (MatrixSerde.cu:765-768)."""
+    p = _snap_params(gpu)
+    seed = gpu.GpuRngSeed.from_bytes(bytes(range(1, 33)))
+    m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 2, 2, gpu.GPU_MATRIX_DIST_UNIFORM, 0.0, seed)
+    tight = m.bytes_per_poly()
+    stride = tight + 64
+    out = bytearray(b"\xa5" * (4 * stride))
+    m.store_rns_bytes(out, stride, gpu.GPU_POLY_FORMAT_EVAL)
+    wire = m.to_rns().tobytes()
+    for i in range(4):
+        assert out[i * stride : i * stride + tight] == wire[i * tight : (i + 1) * tight]
+        assert out[i * stride + tight : (i + 1) * stride] == b"\xa5" * 64
+    back = gpu.GpuDCRTPolyMatrix.new_empty(p, 2, 2)
+    back.is_ntt = False
+    back.load_rns_bytes(bytes(out), stride, gpu.GPU_POLY_FORMAT_EVAL)
+    assert back.is_ntt and back == m
+    with pytest.raises(RuntimeError, match="format conversion is not supported"):
+        m.store_rns_bytes(out, stride, gpu.GPU_POLY_FORMAT_COEFF)
+    m.store_rns_bytes(bytearray(), stride, gpu.GPU_POLY_FORMAT_EVAL)  # empty buffer: a no-op, as in the reference
+    # the constant-coefficient store with a wider stride: words beyond the limb count stay as they were (MatrixSerde.cu:1041-1049)
+    from mxx_amd import _ffi
+
+    mc = m.into_coeff_domain()
+    words = np.full((4, 5), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
+    ev = C.c_void_p()
+    assert _ffi.lib().gpu_matrix_store_const_coeff_batch(mc.raw, words.ctypes.data, 5, C.byref(ev)) == 0
+    _ffi.wait_and_destroy_events(ev)
+    assert np.array_equal(words[:, :3], mc.store_const_coeff_words().reshape(4, 3)) and (words[:, 3:] == 0xA5A5A5A5A5A5A5A5).all()
+    m = mc.ensure_eval()
+    poly = m.entry(1, 0)
+    buf = bytearray(tight)
+    poly.store_rns_bytes(buf, gpu.GPU_POLY_FORMAT_EVAL)
+    assert bytes(buf) == wire[2 * tight : 3 * tight]
+    assert gpu.one_rns_bytes(p) == gpu.GpuDCRTPoly.const_one(p).inner.to_rns().tobytes()
+    one = np.frombuffer(gpu.one_rns_bytes(p), dtype="<u8")
+    assert one.size == 3 * 256 and (one == 1).all()  # the constant 1 evaluates to 1 in every slot of every limb
+
+
+def test_read_from_files_blocks(gpu, tmp_path, monkeypatch):
+    """a 5 x 3 matrix stored as BLOCK_SIZE = 2 blocks in the reference's file naming and bincode framing reads back
+    entry for entry; a short entry is zero-padded and a missing file is an error naming it"""
+    from mxx_amd.matrix import _bincode_nested_bytes
+
+    p = _snap_params(gpu)
+    seed = gpu.GpuRngSeed.from_bytes(bytes(range(2, 34)))
+    m = gpu.GpuDCRTPolyMatrix.sample_distribution(p, 5, 3, gpu.GPU_MATRIX_DIST_UNIFORM, 0.0, seed)
+    wire = m.to_rns()  # EVAL
+    monkeypatch.setenv("BLOCK_SIZE", "2")
+    bsize = 2
+    ro, co = gpu.block_offsets(range(0, 5), bsize), gpu.block_offsets(range(0, 3), bsize)
+    assert ro == [0, 2, 4, 5] and co == [0, 2, 3]
+    for r0, r1 in zip(ro, ro[1:]):
+        for c0, c1 in zip(co, co[1:]):
+            entries = [[wire[i, j].tobytes() for j in range(c0, c1)] for i in range(r0, r1)]
+            if (r0, c0) == (4, 2):
+                entries[0][0] = entries[0][0][: 256 * 8]  # only limb 0 on file: the rest reads as zero
+            (tmp_path / f"mat_{bsize}_{r0}.{r1}_{c0}.{c1}.matrix").write_bytes(_bincode_nested_bytes(entries))
+    got = gpu.GpuDCRTPolyMatrix.read_from_files(p, 5, 3, tmp_path, "mat")
+    want = wire.copy()
+    want[4, 2, 1:] = 0
+    assert got.is_ntt and np.array_equal(got.to_rns(), want)
+    with pytest.raises(RuntimeError, match="Failed to read matrix file"):
+        gpu.GpuDCRTPolyMatrix.read_from_files(p, 5, 3, tmp_path, "absent")
+
+
+def test_poly_from_u64_vecs_sets_level_and_stays_coeff(gpu):
+    p = _snap_params(gpu)
+    moduli = p.moduli()
+    coeffs = [[5, 6], [7], [], [9, 10]]  # two limbs at most -> level 1; missing residues are zero
+    poly = gpu.GpuDCRTPoly.from_u64_vecs(p, coeffs)
+    assert poly.level() == 1 and not poly.is_ntt()
+    res = poly.inner.to_rns()[0, 0]
+    assert res.shape == (2, 256)
+    assert list(res[0, :5]) == [5, 7, 0, 9, 0] and list(res[1, :5]) == [6, 0, 0, 10, 0]
+    full = gpu.GpuDCRTPoly.from_u64_vecs(p, [[1 % q for q in moduli]])
+    assert full.level() == 2
+    full.ntt_in_place()
+    assert full == gpu.GpuDCRTPoly.const_one(p)
+    with pytest.raises(AssertionError, match="exceeds CRT depth"):
+        gpu.GpuDCRTPoly.from_u64_vecs(p, [[1, 2, 3, 4]])
+    with pytest.raises(AssertionError, match="same level"):
+        poly.assert_compatible(full)

@@ -69,3 +69,42 @@ def test_dist_type_ffi_codes():
     assert mx.DistType.GaussDist(3.2).as_ffi() == 1
     assert mx.DistType.BitDist().as_ffi() == 2
     assert mx.DistType.TernaryDist().as_ffi() == 3
+
+
+def test_block_offsets_and_bincode_block_framing():
+    """host helpers of the stored-matrix reader (gpu_dcrt_poly.rs:1594-1641,1899-1909): no device involved"""
+    from mxx_amd.matrix import _bincode_nested_bytes, _bincode_read_nested_bytes, block_offsets, block_size
+
+    assert block_offsets(range(0, 5), 2) == [0, 2, 4, 5]
+    assert block_offsets(range(3, 9), 3) == [3, 6, 9]
+    assert block_offsets(range(0, 0), 4) == [0]
+    assert block_size() == int(__import__("os").environ.get("BLOCK_SIZE", "100"))
+    entries = [[b"", b"\x01" * 250, b"\x02" * 251], [b"\x03" * 70000]]  # lengths on both sides of bincode's 1 / 3 / 5-byte varints
+    blob = _bincode_nested_bytes(entries)
+    assert blob[:2] == bytes([2, 3]) and blob[2] == 0 and blob[3] == 250 and blob[254] == 251  # 251 -> tag byte, then u16
+    assert _bincode_read_nested_bytes(blob) == entries
+
+
+def test_rns_snapshot_validation_without_a_device():
+    from mxx_amd.matrix import GpuDCRTMatrixRnsSnapshot, rns_bytes_len, rns_bytes_len_for_level
+
+    class P:  # the two accessors the checks use
+        def crt_depth(self):
+            return 3
+
+        def ring_dimension(self):
+            return 16
+
+    assert rns_bytes_len_for_level(P(), 0) == 128 and rns_bytes_len(P()) == 384
+    with pytest.raises(AssertionError):
+        rns_bytes_len_for_level(P(), 3)
+    ok = GpuDCRTMatrixRnsSnapshot(2, 1, 1, False, 256, bytes(512))
+    ok.validate_for_params(P())
+    assert ok == GpuDCRTMatrixRnsSnapshot(2, 1, 1, False, 256, bytearray(512)) and ok != GpuDCRTMatrixRnsSnapshot(2, 1, 1, True, 256, bytes(512))
+    for bad, msg in [
+        (GpuDCRTMatrixRnsSnapshot(2, 1, 3, False, 512, bytes(1024)), "invalid RNS snapshot level"),
+        (GpuDCRTMatrixRnsSnapshot(2, 1, 1, False, 264, bytes(528)), "bytes_per_poly mismatch"),
+        (GpuDCRTMatrixRnsSnapshot(2, 1, 1, False, 256, bytes(511)), "byte length mismatch"),
+    ]:
+        with pytest.raises(AssertionError, match=msg):
+            bad.validate_for_params(P())
