@@ -36,12 +36,15 @@ from .sampler import (  # noqa: F401
     hash_seed_for_matrix,
     keccak256,
     random_gpu_rng_seed,
+    sample_gpu_matrix_native,
     sample_gpu_matrix_with_seed,
     sample_gpu_matrix_with_seed_columns,
 )
 from .trapdoor import (  # noqa: F401
     GpuDCRTPolyTrapdoorSampler,
     GpuDCRTTrapdoor,
+    GpuPerturbationSamples,
+    coeff_cached_matrix,
     compute_preimage_norm,
     p1_covariance_parameters,
     preimage_c,

@@ -223,6 +223,16 @@ class GpuDCRTPolyParams:
         self._ctx = _cached_context(self._n, self._moduli, self._base_bits, self._gpu_ids, self._dnum)
 
     @classmethod
+    def new(cls, ring_dimension: int, moduli, base_bits: int) -> "GpuDCRTPolyParams":
+        return cls(ring_dimension, moduli, base_bits)
+
+    @classmethod
+    def new_with_gpu(cls, ring_dimension: int, moduli, base_bits: int, gpu_ids, dnum=None) -> "GpuDCRTPolyParams":
+        """gpu.rs:567-594: explicit device list; dnum defaults to the number of devices (1 for an empty list)."""
+        gpu_ids = list(gpu_ids)
+        return cls(ring_dimension, moduli, base_bits, gpu_ids=gpu_ids, dnum=dnum if dnum is not None else max(len(gpu_ids), 1))
+
+    @classmethod
     def from_cpu_params(cls, params: DCRTPolyParams, gpu_ids=None) -> "GpuDCRTPolyParams":
         moduli, _, _ = params.to_crt()
         return cls(params.ring_dimension(), moduli, params.base_bits(), gpu_ids=gpu_ids)
@@ -275,6 +285,15 @@ class GpuDCRTPolyParams:
         out = 1
         for q in self._moduli[: level + 1]:
             out *= q
+        return out
+
+    def reconstruct_coeffs_for_level(self, level: int) -> list:
+        """CRT weights (Q / q_i) * ((Q / q_i)^-1 mod q_i) mod Q for the limbs 0..=level (gpu.rs:620-635)."""
+        Q = self.modulus_for_level(level)
+        out = []
+        for q in self._moduli[: level + 1]:
+            Qi = Q // q
+            out.append(Qi * pow(Qi % q, -1, q) % Q)
         return out
 
     def __eq__(self, other):

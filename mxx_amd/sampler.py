@@ -135,6 +135,11 @@ def sample_gpu_matrix_with_seed(params, nrow, ncol, dist: DistType, seed: GpuRng
     return GpuDCRTPolyMatrix.sample_distribution(params, nrow, ncol, dist.as_ffi(), dist.sigma, seed)
 
 
+def sample_gpu_matrix_native(params, nrow, ncol, dist: DistType) -> GpuDCRTPolyMatrix:
+    """a fresh seed per call (sampler/gpu.rs:144-151)"""
+    return sample_gpu_matrix_with_seed(params, nrow, ncol, dist, random_gpu_rng_seed())
+
+
 def sample_gpu_matrix_with_seed_columns(params, nrow, total_ncol, col_start, col_len, dist, seed):
     if nrow == 0 or col_len == 0:
         return GpuDCRTPolyMatrix.zero(params, nrow, col_len)

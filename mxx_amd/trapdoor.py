@@ -45,6 +45,21 @@ def _coeff_cached(m: GpuDCRTPolyMatrix) -> GpuDCRTPolyMatrix:
     return m.clone().into_coeff_domain()
 
 
+coeff_cached_matrix = _coeff_cached  # gpu.rs:28-30
+
+
+class GpuPerturbationSamples:
+    """(p1, p2) of `sample_pert_square_mat_gpu_native_parts` (gpu.rs:32-35)."""
+
+    __slots__ = ("p1", "p2")
+
+    def __init__(self, p1, p2):
+        self.p1, self.p2 = p1, p2
+
+    def __iter__(self):
+        return iter((self.p1, self.p2))
+
+
 class GpuDCRTTrapdoor:
     """R, E ~ D_sigma^{d x dk} plus the coefficient-domain RR^T, RE^T, EE^T caches (gpu.rs:46-80)."""
 
@@ -76,6 +91,8 @@ class GpuDCRTTrapdoor:
             )
             self._p1_cache = ((c, s, dgg_stddev), cache)
             return cache
+
+    get_or_create_p1_covariance_cache = p1_covariance_cache  # gpu.rs:137-200
 
     def public_matrix_parts(self, public_matrix: GpuDCRTPolyMatrix):
         """(left, right, [R; E; right]) of A = [left | right] for this trapdoor: the two column blocks the preimage multiplies
@@ -166,6 +183,19 @@ class GpuDCRTPolyTrapdoorSampler:
     def _sample_pert(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol):
         """`sample_pert_square_mat_gpu_native_parts` (gpu.rs:423-474): (p1, p2), the reference's signature."""
         return self._sample_pert_parts(params, td, s, c, dgg_stddev, sigma_large, total_ncol)[:2]
+
+    def sample_pert_square_mat_gpu_native_parts(self, params, td, s, c, dgg_stddev, sigma_large, total_ncol):
+        return GpuPerturbationSamples(*self._sample_pert(params, td, s, c, dgg_stddev, sigma_large, total_ncol))
+
+    def sample_pert_square_mat_gpu_native(self, params, td, s, c, dgg_stddev, sigma_large, total_ncol):
+        """p_hat = [p1; p2] cut to the `total_ncol` target columns (gpu.rs:502-541: the padding columns of the last
+        d-block are sampled and skipped at assembly)."""
+        p1, p2 = self._sample_pert(params, td, s, c, dgg_stddev, sigma_large, total_ncol)
+        assert p1.col_size() >= total_ncol and p2.col_size() >= total_ncol, "p1 / p2 must include the target columns"
+        p_hat = GpuDCRTPolyMatrix(params, p1.row_size() + p2.row_size(), total_ncol, p1.level, p1.is_ntt)
+        p_hat.copy_block_from(p1, 0, 0, 0, 0, p1.row_size(), total_ncol)
+        p_hat.copy_block_from(p2, p1.row_size(), 0, 0, 0, p2.row_size(), total_ncol)  # both samplers finish in EVAL
+        return p_hat
 
     def _sample_pert_parts(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol, stacked=None):
         """The same with the by-products the large-operand assembly reuses.  With `stacked` = [R; E; right] (right = the

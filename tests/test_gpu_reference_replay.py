@@ -523,8 +523,8 @@ def test_gpu_p_hat_coefficients_below_compute_preimage_norm(gpu):
     s = preimage_smoothing_parameter(base, SIGMA, size, n, k)
     dgg_large_std = math.sqrt(s * s - c * c)
     for _sample in range(4):
-        p1, p2 = sampler._sample_pert(p, trapdoor, s, c, SIGMA, dgg_large_std, size)
-        p_hat = p1.slice_columns(0, size).concat_rows([p2.slice_columns(0, size)])  # sample_pert_square_mat_gpu_native, :497-531
+        p_hat = sampler.sample_pert_square_mat_gpu_native(p, trapdoor, s, c, SIGMA, dgg_large_std, size)  # :502-541
+        assert p_hat.size() == (2 * size + size * p.modulus_digits(), size)
         assert _max_centred(p_hat) < bound
 
 

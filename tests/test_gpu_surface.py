@@ -713,3 +713,51 @@ def test_poly_from_u64_vecs_sets_level_and_stays_coeff(gpu):
         gpu.GpuDCRTPoly.from_u64_vecs(p, [[1, 2, 3, 4]])
     with pytest.raises(AssertionError, match="same level"):
         poly.assert_compatible(full)
+
+
+def test_reference_named_constructors_and_perturbation_entry_points(gpu):
+    """`new_with_gpu` / `reconstruct_coeffs_for_level` (gpu.rs:567-635), `sample_gpu_matrix_native` (sampler/gpu.rs:144)
+    and the two perturbation entry points (trapdoor/gpu.rs:423-541) with a target width that is not a multiple of d"""
+    import math
+
+    from mxx_amd.params import DCRTPolyParams
+    from mxx_amd.trapdoor import preimage_c, preimage_smoothing_parameter
+
+    moduli, _b, _d = DCRTPolyParams(64, 3, 24, 12).to_crt()
+    p = gpu.GpuDCRTPolyParams.new_with_gpu(64, moduli, 12, gpu.detected_gpu_device_ids()[:1])
+    assert p == gpu.GpuDCRTPolyParams.new(64, moduli, 12) and p.crt_depth() == 3
+    for level in range(3):
+        Q = p.modulus_for_level(level)
+        w = p.reconstruct_coeffs_for_level(level)
+        assert len(w) == level + 1
+        for i, wi in enumerate(w):  # the CRT idempotents: 1 mod q_i, 0 mod every other limb of the level
+            assert 0 <= wi < Q and all(wi % q == (1 if j == i else 0) for j, q in enumerate(moduli[: level + 1]))
+    x = 123456789012345 % p.modulus()
+    poly = gpu.GpuDCRTPoly.from_biguint_to_constant(p, x)
+    res = poly.ensure_coeff_domain().inner.to_rns()[0, 0, :, 0]
+    assert sum(int(r) * wi for r, wi in zip(res, p.reconstruct_coeffs_for_level(2))) % p.modulus() == x
+
+    a = gpu.sample_gpu_matrix_native(p, 2, 3, gpu.DistType.BitDist())
+    b = gpu.sample_gpu_matrix_native(p, 2, 3, gpu.DistType.BitDist())
+    assert a.size() == (2, 3) and a != b  # a fresh seed per call
+    assert gpu.sample_gpu_matrix_native(p, 0, 3, gpu.DistType.BitDist()).size() == (0, 3)
+
+    sigma, d, cols = 4.578, 2, 3  # 3 target columns, d = 2: the last block is padded to 4 and cut again
+    sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, sigma)
+    td, _pub = sampler.trapdoor(p, d)
+    n, k, base = p.ring_dimension(), p.modulus_digits(), 1 << p.base_bits()
+    c = preimage_c(base, sigma)
+    s = preimage_smoothing_parameter(base, sigma, d, n, k)
+    large = math.sqrt(s * s - c * c)
+    from mxx_amd.sampler import seed_source
+
+    with seed_source([bytes([i] * 32) for i in (1, 2)]):
+        parts = sampler.sample_pert_square_mat_gpu_native_parts(p, td, s, c, sigma, large, cols)
+    assert parts.p1.size() == (2 * d, 4) and parts.p2.size() == (d * k, 4)
+    with seed_source([bytes([i] * 32) for i in (1, 2)]):
+        p_hat = sampler.sample_pert_square_mat_gpu_native(p, td, s, c, sigma, large, cols)
+    assert p_hat.size() == (2 * d + d * k, cols) and p_hat.is_ntt
+    assert p_hat.slice(0, 2 * d, 0, cols) == parts.p1.slice_columns(0, cols)
+    assert p_hat.slice(2 * d, 2 * d + d * k, 0, cols) == parts.p2.slice_columns(0, cols)
+    assert td.get_or_create_p1_covariance_cache(c, s, sigma) is td.p1_covariance_cache(c, s, sigma)
+    assert gpu.coeff_cached_matrix(td.r * td.r.transpose()) == td.a_mat_coeff
