@@ -181,11 +181,29 @@ __global__ void gq_tower_kernel(GqTower *__restrict__ towers, const LimbConst *_
 // Pass 1, fully convergent: the dpt normals every element draws first (draws 0..8*dpt-1 = 64-bit words 0..2*dpt-1 of
 // keystream block 0) and the centres a_d they imply.  a_out is [dpt][total]; the 8 - 2*dpt 64-bit words of block 0 the
 // normals did not use are handed to pass 2 in left_out ([8 - 2*dpt][total]).
+// l_d / h_d of the perturbation's Cholesky-like recurrence (MatrixTrapdoor.cu:701-833): functions of (base, dpt, d) only,
+// evaluated once on the host (IEEE sqrt and division: the same bits as the device's) instead of per element - four
+// square roots and four divisions of the prep kernel's ~1475 instructions per element
+struct GqPertConsts {
+    double ld[4], hn[4];  // pd = ld[d] z_d + hn[d] z_{d+1} for d + 1 < dpt, hn[d - 1] z_d for the last digit (0 when dpt = 1)
+};
+
+static inline GqPertConsts gq_pert_consts(uint32_t dpt, uint32_t base_bits) {
+    GqPertConsts k{};
+    const double base_f = static_cast<double>(1ull << base_bits), kf = static_cast<double>(dpt);
+    for (uint32_t d = 0; d < 4 && d < dpt; ++d) {
+        k.ld[d] = d == 0 ? sqrt(base_f * (1.0 + 1.0 / kf) + 1.0) : sqrt(base_f * (1.0 + 1.0 / (kf - static_cast<double>(d))));
+        k.hn[d] = sqrt(base_f * (1.0 - 1.0 / (kf - static_cast<double>(d))));
+    }
+    return k;
+}
+
 template <typename W, int MAXD>
 __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict__ a_out, uint64_t *__restrict__ left_out,
                                        const W *__restrict__ src, const LimbConst *__restrict__ limbs,
                                        ChaChaKey key, size_t total, uint32_t L, uint32_t logN,
-                                       uint32_t dpt, uint32_t base_bits, double c) {
+                                       uint32_t dpt, uint32_t base_bits, double c, GqPertConsts pc) {
+    static_assert(MAXD <= 4, "GqPertConsts holds four digits");
     const size_t idx = item_index();
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
@@ -197,7 +215,6 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
     const uint64_t base = 1ull << base_bits;
     const double base_f = static_cast<double>(base);
     const double sigma = c / (base_f + 1.0);
-    const double kf = static_cast<double>(dpt);
 
     uint64_t w[8];
     chacha_block_words(key, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 0, w);
@@ -212,16 +229,9 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) {
         if (d < (int)dpt) {
-            const double ld = d == 0 ? sqrt(base_f * (1.0 + 1.0 / kf) + 1.0)
-                                     : sqrt(base_f * (1.0 + 1.0 / (kf - static_cast<double>(d))));
             double pd;
-            if (d + 1 < (int)dpt) {
-                const double hn = sqrt(base_f * (1.0 - 1.0 / (kf - static_cast<double>(d))));
-                pd = ld * zf[d] + hn * zf[d + 1 < MAXD ? d + 1 : d];
-            } else {
-                const double hd = d == 0 ? 0.0 : sqrt(base_f * (1.0 - 1.0 / (kf - static_cast<double>(d - 1))));
-                pd = hd * zf[d];
-            }
+            if (d + 1 < (int)dpt) pd = pc.ld[d] * zf[d] + pc.hn[d] * zf[d + 1 < MAXD ? d + 1 : d];
+            else pd = (d == 0 ? 0.0 : pc.hn[d - 1 < 0 ? 0 : d - 1]) * zf[d];
             const double vd = static_cast<double>(static_cast<int64_t>((value >> (base_bits * d)) & (base - 1)));
             const double ad = (prev_a + vd - pd) / base_f;
             prev_a = ad;
@@ -418,7 +428,7 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
     MXX_TRACE_BYTES(static_cast<double>(total) * (sizeof(W) + 8.0 * (8 - dpt)));
     MXX_LAUNCH((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
                        ctx->stream, a_words, left_words, src, ctx->d_limbs, key, total, L,
-                       ctx->logN, dpt, base_bits, c);
+                       ctx->logN, dpt, base_bits, c, gq_pert_consts(dpt, base_bits));
     const uint32_t per_lane =
         sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD, KARNEY_SERVICES>), ctx->device, ctx->env.sampler_per_lane);
     const unsigned blocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
