@@ -43,6 +43,7 @@ struct EnvSwitches {
     char matmul_path = 0;         // MXX_HIP_MATMUL_PATH: 0 auto, 'r' reg, 'l' lds, 'd' dma, 'w' dma32 (wide tile), 'm' mfma
     int matmul_tile = 0;          // MXX_HIP_MATMUL_TILE=RCS[p] (tuning: rows, cols, slots per lane of the register tile, p = loads ahead)
     bool gsamp_simple = false;    // MXX_HIP_GSAMP=simple
+    bool gsamp_no_uni = false;    // MXX_HIP_GSAMP=nouni: the lane kernel's per-element tower look-up even when chunks are uniform (A/B, tests)
     bool p1_simple = false;       // MXX_HIP_P1=simple
     int sampler_per_lane = 0;     // MXX_HIP_SAMPLER_PER_LANE (0 = sized for one resident round)
     int sampler_fill_every = 0;   // MXX_HIP_SAMPLER_FILL_EVERY = 1..8: keystream refill cadence of the Gaussian lane kernels in checkpoints (0 = per kernel default)

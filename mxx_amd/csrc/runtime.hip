@@ -258,7 +258,10 @@ void EnvSwitches::load() {
     if (const char *e = std::getenv("MXX_HIP_MATMUL_TILE")) {
         if (e[0] && e[1] && e[2]) matmul_tile = ((e[0] - '0') * 100 + (e[1] - '0') * 10 + (e[2] - '0')) * 2 + (e[3] == 'p');
     }
-    if (const char *e = std::getenv("MXX_HIP_GSAMP")) gsamp_simple = e[0] == 's';
+    if (const char *e = std::getenv("MXX_HIP_GSAMP")) {
+        gsamp_simple = e[0] == 's';
+        gsamp_no_uni = e[0] == 'n';
+    }
     if (const char *e = std::getenv("MXX_HIP_P1")) p1_simple = e[0] == 's';
     if (const char *e = std::getenv("MXX_HIP_NTT64")) ntt64_int = e[0] == 'i';
     if (const char *e = std::getenv("MXX_HIP_RNG_COMPAT")) rng_compat = e[0] == 'r';

@@ -248,7 +248,11 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 // Pass 2: the dpt Karney integers of every element.  Wave w owns elements [w*64*per_lane,
 // +64*per_lane) and its lanes take them one at a time (wave_take, rng.h).
 // ph = index of the integer in flight (0: z_last, 1+d: z_d).
-template <typename W, int MAXD, int SV>
+// UNI: every wave's chunk lies inside ONE (polynomial, tower) vector (the launcher checks that 64 * per_lane divides n):
+// the tower's constants, the polynomial index and the division that finds them are then per-WAVE scalars, read once
+// with scalar loads, instead of a 32-bit division and eleven vector loads with their waits in every element hand-over
+// (the second stall, c_d of the tower at the first integer's hand-over, goes with them).
+template <typename W, int MAXD, int SV, bool UNI = false>
 __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage,
                                         const LimbConst *__restrict__ limbs, ChaChaKey key,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
@@ -262,6 +266,10 @@ __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(in
     const int last = static_cast<int>(dpt) - 1;
     const uint32_t nleft = 8 - 2 * dpt;
     WaveChunk chunk = wave_chunk(total, per_lane);
+    // UNI: (p, t) of the whole chunk and the tower's record, wave-uniform
+    const uint32_t pt_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(chunk.base >> logN)));
+    const uint32_t p_u = pt_u / L, t_u = pt_u - p_u * L;
+    const GqTower tw_u = towers[UNI ? t_u : 0];
 
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0);
@@ -287,7 +295,7 @@ __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(in
                 const double zl = static_cast<double>(z_last);
 #pragma unroll
                 for (int d = 0; d < MAXD; ++d)
-                    if (d < (int)dpt) a[d] += zl * towers[tower].cvec[d];  // c_d: per tower, from gq_tower_kernel
+                    if (d < (int)dpt) a[d] += zl * (UNI ? tw_u.cvec[d] : towers[tower].cvec[d]);  // c_d: per tower, from gq_tower_kernel
             } else {
 #pragma unroll
                 for (int d = 0; d < MAXD; ++d)
@@ -321,8 +329,15 @@ __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(in
             if (have) {
                 idx = chunk.base + e;
                 const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
-                const uint32_t pt = static_cast<uint32_t>(idx >> logN);
-                const uint32_t p = pt / L, t = pt - p * L;
+                uint32_t p, t;
+                if constexpr (UNI) {
+                    p = p_u;
+                    t = t_u;
+                } else {
+                    const uint32_t pt = static_cast<uint32_t>(idx >> logN);
+                    p = pt / L;
+                    t = pt - p * L;
+                }
                 tower = t;
                 // block 0 went to pass 1: its unused words are draws 8*dpt..31 of the stream, continue at block 1
                 rng_reopen(rng, gadget_stream0(i, t), static_cast<uint64_t>(p) + 1, 1);
@@ -344,8 +359,12 @@ __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(in
                 }
                 ph = 0;
                 fin = false;
-                const GqTower tw = towers[t];
-                karney_begin(f, -a_last / tw.c_last, tw.sd, tw.div);
+                if constexpr (UNI) {
+                    karney_begin(f, -a_last / tw_u.c_last, tw_u.sd, tw_u.div);
+                } else {
+                    const GqTower tw = towers[t];
+                    karney_begin(f, -a_last / tw.c_last, tw.sd, tw.div);
+                }
             } else {
                 f.st = KS_IDLE;
             }
@@ -434,13 +453,20 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
     const unsigned blocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * (8 - dpt) + 8.0 * dpt));  // pass 1's words read, dpt int64 digits written
-#define LAUNCH_GL(SV)                                                                                                       \
-    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD, SV>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream,                 \
+    // a chunk of 64 * per_lane consecutive elements inside one (polynomial, tower) vector: the kernel's UNI form
+    const bool uni = (static_cast<size_t>(ctx->N) % (static_cast<size_t>(SAMPLER_THREADS) * per_lane)) == 0 && !ctx->env.gsamp_no_uni;
+#define LAUNCH_GL(SV, UNI)                                                                                                  \
+    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD, SV, UNI>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream,            \
                static_cast<int64_t *>(stage), ctx->d_limbs, key, static_cast<const GqTower *>(towers), a_words, left_words, \
                total, src_cols, L, ctx->logN, dpt, base_bits, c, karney_divisor(sigma), per_lane,                           \
                static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3))
-    if (per_lane == 1) LAUNCH_GL(1);
-    else LAUNCH_GL(KARNEY_SERVICES);
+    if (per_lane == 1) {
+        if (uni) LAUNCH_GL(1, true);
+        else LAUNCH_GL(1, false);
+    } else {
+        if (uni) LAUNCH_GL(KARNEY_SERVICES, true);
+        else LAUNCH_GL(KARNEY_SERVICES, false);
+    }
 #undef LAUNCH_GL
     // the int64 digits and the residue read; every digit written as a residue of every limb (the call's output: 655 MB at M3A)
     MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * dpt + sizeof(W) + static_cast<double>(dpt) * L * sizeof(W)));
