@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
     const size_t total = (polys << logN) >> glog;  // groups
     WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
-    rng_init_keyed(rng, ring, key, 0, 0);
+    rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
     KarneyFsm f;
     karney_reset(f);
     bool have = false, fin = true;

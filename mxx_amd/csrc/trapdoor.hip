@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(in
     const GqTower tw_u = towers[UNI ? t_u : 0];
 
     ChaChaRng rng;
-    rng_init_keyed(rng, ring, key, 0, 0);
+    rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
     KarneyFsm f;
     karney_reset(f);
     bool fin = true, have = false;
@@ -666,7 +666,7 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) p1_sample_lanes_kernel(int64_
     __shared__ uint32_t ring[SAMPLER_THREADS * RNG_RING_SLOTS];  // 128 bytes per lane: 8 KB per one-wave workgroup
     WaveChunk chunk = wave_chunk(total, per_lane);
     ChaChaRng rng;
-    rng_init_keyed(rng, ring, key, 0, 0);
+    rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
     KarneyFsm f;
     karney_reset(f);
     bool fin = true, have = false;
