@@ -155,7 +155,10 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 #ifndef GAUSS_GROUP_LOG
 #define GAUSS_GROUP_LOG 1  // two coefficients per stream (the CPU restatement's keying: oracle/oracle_sampling.c)
 #endif
-template <int SV>
+// UNI: every wave's chunk of groups lies inside one polynomial (the launcher checks that 64 * per_lane divides the groups
+// per polynomial): its (row, column) - a 32-bit division - is then computed once per wave on the scalar unit instead of in
+// every group hand-over
+template <int SV, bool UNI = false>
 __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every,
@@ -165,6 +168,9 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
     const uint32_t G = 1u << glog;
     const size_t total = (polys << logN) >> glog;  // groups
     WaveChunk chunk = wave_chunk(total, per_lane);
+    const uint32_t p_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(chunk.base >> (logN - glog))));
+    const uint32_t row_u = p_u / local_ncol, lcol_u = p_u - row_u * local_ncol;
+    const uint64_t stream0_u = row_u * full_ncol + col_offset + lcol_u + 1;
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
     KarneyFsm f;
@@ -189,9 +195,15 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
                 have = e < chunk.len;
                 if (have) {
                     idx = chunk.base + e;
-                    const uint32_t p = static_cast<uint32_t>(idx >> (logN - glog));
-                    const uint32_t row = p / local_ncol, lcol = p - row * local_ncol;
-                    rng_reopen(rng, row * full_ncol + col_offset + lcol + 1, (idx & ((size_t(1) << (logN - glog)) - 1)) + 1);
+                    uint64_t stream0;
+                    if constexpr (UNI) {
+                        stream0 = stream0_u;
+                    } else {
+                        const uint32_t p = static_cast<uint32_t>(idx >> (logN - glog));
+                        const uint32_t row = p / local_ncol, lcol = p - row * local_ncol;
+                        stream0 = row * full_ncol + col_offset + lcol + 1;
+                    }
+                    rng_reopen(rng, stream0, (idx & ((size_t(1) << (logN - glog)) - 1)) + 1);
                     cnt = 0;
                     fin = false;
                     karney_begin(f, 0.0, sigma, div);
@@ -401,13 +413,20 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
         // one group per lane at most: the call lasts as long as its unluckiest lane's chain, which must not wait for
         // keystream - refills at every checkpoint, one service point per superstep; otherwise every third checkpoint and
         // never forced (64 lanes cannot reach 65)
-#define LAUNCH_SG(SV)                                                                                                          \
-    MXX_LAUNCH(sample_gauss_kernel<SV>, dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream, static_cast<int64_t *>(stage), polys, \
+        const size_t groups_per_poly = static_cast<size_t>(ctx->N) >> (ctx->logN < GAUSS_GROUP_LOG ? ctx->logN : GAUSS_GROUP_LOG);
+        const bool uni = groups_per_poly % (static_cast<size_t>(SAMPLER_THREADS) * per_lane) == 0;
+#define LAUNCH_SG(SV, UNI)                                                                                                     \
+    MXX_LAUNCH((sample_gauss_kernel<SV, UNI>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream, static_cast<int64_t *>(stage), polys, \
                static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,                   \
                static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : (per_lane == 1 ? 1 : 3)),      \
                per_lane == 1 ? 1 : 65)
-        if (per_lane == 1) LAUNCH_SG(1);
-        else LAUNCH_SG(KARNEY_SERVICES);
+        if (per_lane == 1) {
+            if (uni) LAUNCH_SG(1, true);
+            else LAUNCH_SG(1, false);
+        } else {
+            if (uni) LAUNCH_SG(KARNEY_SERVICES, true);
+            else LAUNCH_SG(KARNEY_SERVICES, false);
+        }
 #undef LAUNCH_SG
         const hipError_t err = hipGetLastError();
         const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
