@@ -580,14 +580,16 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
         uint32_t w1;
         uint64_t w2;
         rng_next16_u64(rng, w1, w2);
-        const int64_t s = (w1 & 1u) ? 1 : -1;
-        const double di0 = f.stddev * static_cast<double>(f.k) + static_cast<double>(s) * f.mean;
-        const int64_t i0 = static_cast<int64_t>(ceil(di0));
-        const double x0 = (static_cast<double>(i0) - di0) / f.stddev;
+        // s = +-1.  s * mean is +-mean exactly and (double)(int64)ceil(d) is ceil(d) itself (|d| < 2^63): the same values as
+        // the sequential form's `s * mean` and `(double)i0` without an int64 <-> double round trip in the service block
+        const bool neg = (w1 & 1u) == 0;
+        const double di0 = f.stddev * static_cast<double>(f.k) + (neg ? -f.mean : f.mean);
+        const double ci0 = ceil(di0);
+        const double x0 = (ci0 - di0) / f.stddev;
         uint64_t j = w2 - __umul64hi(w2, f.magic) * f.cs;  // w2 % cs
         while (j >= f.cs) j -= f.cs;
         const double x = x0 + static_cast<double>(static_cast<int64_t>(j)) / f.stddev;
-        if (!(x < 1.0) || (x == 0.0 && s < 0 && f.k == 0)) {
+        if (!(x < 1.0) || (x == 0.0 && neg && f.k == 0)) {
             const int32_t it = f.iter + 1;
             f.iter = it;
             f.k = 0;
@@ -605,7 +607,8 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
             f.T_hi = f.xt_hi;
             f.cnt = 0;
             f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
-            f.result = s * (i0 + static_cast<int64_t>(j));
+            const int64_t mag = static_cast<int64_t>(ci0) + static_cast<int64_t>(j);
+            f.result = neg ? -mag : mag;
             f.st = KS_B;
         }
     } else if (f.st == KS_TIE && rng_avail(rng) >= 2 * ((KARNEY_LO_BITS + RNG_DRAW_BITS - 1) / RNG_DRAW_BITS)) {
