@@ -420,7 +420,8 @@ struct KarneyFsm {
     uint32_t xt_hi, bt_hi;     // x and (2k+x)/(2k+2) in ticks of 2^-53, top parts
     uint32_t tie_h, tie_st;    // the draw that tied and the state it tied in
     uint32_t T_own_cnt, zz_own_cnt;
-    uint64_t T_lo, zz_lo, xt_lo, bt_lo;
+    uint64_t T_lo, zz_lo;
+    double x;                  // the trial's x: the low bits of its two constant thresholds are rebuilt from it when a tie needs them
     double mean, stddev;
     uint64_t cs, magic;  // ceil(stddev) and floor((2^64-1)/cs)
     int64_t result;
@@ -433,6 +434,13 @@ struct KarneyFsm {
 
 // t in [0, 1] -> ceil(t * 2^53)
 __device__ __forceinline__ uint64_t karney_ticks(double t) { return static_cast<uint64_t>(ceil(t * 9007199254740992.0)); }
+// the top part of the same: ticks >> 37 without leaving double precision (both scalings are exact; the conversion truncates)
+__device__ __forceinline__ uint32_t karney_ticks_hi(double t) {
+    return static_cast<uint32_t>(ldexp(ceil(t * 9007199254740992.0), -KARNEY_LO_BITS));
+}
+__device__ __forceinline__ double karney_b1_threshold(int32_t k, double x) {
+    return (2.0 * static_cast<double>(k) + x) / static_cast<double>(2 * k + 2);
+}
 
 struct KarneyDivisor {
     uint64_t cs, magic;
@@ -458,7 +466,8 @@ __device__ __forceinline__ void karney_reset(KarneyFsm &f) {
     f.in_p = false;
     f.T_hi = f.zz_hi = f.xt_hi = f.bt_hi = f.tie_h = f.tie_st = 0;
     f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
-    f.T_lo = f.zz_lo = f.xt_lo = f.bt_lo = 0;
+    f.T_lo = f.zz_lo = 0;
+    f.x = 0.0;
     f.mean = f.stddev = 0.0;
     f.cs = 1;
     f.magic = 0;
@@ -598,12 +607,11 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
             if (it >= (1 << 16)) f.st = KS_FALLBACK;
         } else {
             f.b_left = f.k + 1;
-            const uint64_t xt = karney_ticks(x);
-            const uint64_t bt = karney_ticks((2.0 * static_cast<double>(f.k) + x) / static_cast<double>(2 * f.k + 2));
-            f.xt_hi = static_cast<uint32_t>(xt >> KARNEY_LO_BITS);
-            f.xt_lo = xt & KARNEY_LO_MASK;
-            f.bt_hi = static_cast<uint32_t>(bt >> KARNEY_LO_BITS);
-            f.bt_lo = bt & KARNEY_LO_MASK;
+            // only the top 16 bits of the two constant thresholds are needed until a comparison ties (one in 65536): the low
+            // 37 are rebuilt from x in the tie path instead of being extracted and carried here
+            f.x = x;
+            f.xt_hi = karney_ticks_hi(x);
+            f.bt_hi = karney_ticks_hi(karney_b1_threshold(f.k, x));
             f.T_hi = f.xt_hi;
             f.cnt = 0;
             f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
@@ -620,9 +628,9 @@ __device__ __forceinline__ void karney_heavy(KarneyFsm &f, RNG &rng) {
             else if (f.T_own_cnt == f.cnt) tlo = f.T_lo;
             else tlo = karney_draw_lo(rng, f.T_hi);
         } else if (odd) {  // B1: (2k+x)/(2k+2)
-            tlo = f.bt_lo;
+            tlo = karney_ticks(karney_b1_threshold(f.k, f.x)) & KARNEY_LO_MASK;
         } else {  // B0: x at the start of the run, then y = the z of two comparisons ago
-            if (f.cnt == 0) tlo = f.xt_lo;
+            if (f.cnt == 0) tlo = karney_ticks(f.x) & KARNEY_LO_MASK;
             else if (f.zz_own_cnt == f.cnt - 2) tlo = f.zz_lo;
             else tlo = karney_draw_lo(rng, f.T_hi);
         }
