@@ -482,6 +482,27 @@ __device__ __forceinline__ void karney_open_h(KarneyFsm &f) {
     f.T_own_cnt = f.zz_own_cnt = KARNEY_NO_OWN;
 }
 
+// karney_begin for a sampler whose centre and width never change (the Gaussian matrix): the caller sets mean, stddev, cs
+// and magic ONCE after karney_reset (karney_fix_parameters) and they stay wave-uniform loop invariants - scalar registers -
+// instead of being re-assigned, lane by lane, at every integer
+__device__ __forceinline__ void karney_fix_parameters(KarneyFsm &f, double mean, double stddev, const KarneyDivisor &d) {
+    f.mean = mean;
+    f.stddev = stddev;
+    f.cs = d.cs;
+    f.magic = d.magic;
+}
+__device__ __forceinline__ void karney_begin_fixed(KarneyFsm &f, bool degenerate) {
+    if (degenerate) {  // not finite / not positive width or centre: the sequential form returns llround(mean) without drawing
+        f.result = static_cast<int64_t>(llround(f.mean));
+        f.st = KS_DONE;
+        return;
+    }
+    karney_open_h(f);
+    f.k = 0;
+    f.in_p = false;
+    f.iter = 0;
+}
+
 __device__ __forceinline__ void karney_begin(KarneyFsm &f, double mean, double stddev, const KarneyDivisor &d) {
     f.mean = mean;
     f.stddev = stddev;

@@ -175,6 +175,8 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
     rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
     KarneyFsm f;
     karney_reset(f);
+    karney_fix_parameters(f, 0.0, sigma, div);  // one centre and one width for the whole matrix
+    const bool degenerate = div.degenerate;
     bool have = false, fin = true;
     uint32_t cnt = 0;
     size_t idx = 0;
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
             stage[(idx << glog) + cnt] = f.result;
             ++cnt;
             if (cnt == G) fin = true;
-            else karney_begin(f, 0.0, sigma, div);
+            else karney_begin_fixed(f, degenerate);
         }
     };
     for (uint32_t step = 0;; ++step) {  // one superstep per iteration
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
                     rng_reopen(rng, stream0, (idx & ((size_t(1) << (logN - glog)) - 1)) + 1);
                     cnt = 0;
                     fin = false;
-                    karney_begin(f, 0.0, sigma, div);
+                    karney_begin_fixed(f, degenerate);
                 } else {
                     f.st = KS_IDLE;
                 }
