@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m2b_decompose", "m2b_mul_decompose", "m3a", "m3b", "m4"])
+    ap.add_argument("--workload", default="default", choices=["default", "m1", "m2a", "m2b", "m2b_decompose", "m2b_mul_decompose", "m3a", "m3b", "m3a_refseq", "m4", "m4_batched"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--gather", default="step", choices=["lazy", "step"],
                     help="sharded runs: all-gather the column blocks (product, preimage) after every step, overlapped with the "
@@ -61,6 +61,8 @@ def parse_args(argv=None):
                     help="N>1 in ONE process, as the reference runs (a context per device, a worker thread per context, the "
                          "exchange through gpupoly_matrix_all_gather_columns - RCCL behind the C ABI, no torch)")
     ap.add_argument("--repeats", type=int, default=10, help="extra repetitions of the K steps for median / min")
+    ap.add_argument("--sustain", type=float, default=5.0,
+                    help="seconds of one contiguous region of the headline workload after the timed K steps (0 = none)")
     ap.add_argument("--no-trace", action="store_true", help="skip the per-kernel launch trace (composed rooflines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget per block")
@@ -241,7 +243,7 @@ class Workload:
         self.mx, self.d, self.args = mx, d, args
         # MXX_BENCH_FORCE_DIST=1 rehearses the sharded path (partition + RCCL gather) with a world of one rank
         self.strong = args.scaling == "strong" and (d.world > 1 or d.active)
-        self.params = mx.GpuDCRTPolyParams(N_RING if self.name != "m4" else 256, self.moduli(mx), self.base_bits(),
+        self.params = mx.GpuDCRTPolyParams(N_RING if not self.name.startswith("m4") else 256, self.moduli(mx), self.base_bits(),
                                            gpu_ids=[device], dnum=d.dnum)
         self.lazy_gather = args.gather == "lazy"
         self.ctx = self.params.ctx()
@@ -660,6 +662,25 @@ class M3B(Preimage):
     name, depth = "m3b", 8
 
 
+class M3ARefSeq(M3A):
+    """M3A through ONLY the entry points the reference's Rust side binds, in the reference's own order
+    (src/sampler/trapdoor/gpu.rs:228-369, :423-474): what an unpatched mxx gets from this library.  The headline M3A block
+    uses the extension sequence (row views, fused NTT + add, one stacked product)."""
+
+    name = "m3a_refseq"
+
+    def setup(self):
+        super().setup()
+        self.desc += "; the reference's own call sequence (no gpupoly_* extension entry)"
+
+    def step(self, i, mark):
+        if mark:
+            self.mark(i, 0)
+        self.x = self.sampler.preimage_reference_sequence(self.params, self.td, self.pub, self.target)
+        if mark:
+            self.mark(i, 1)
+
+
 class M4(Workload):
     """BASELINE configs[4] flavour: the parameter family of tests/test_gpu_ggh15_modp_chain.rs:36-42 (n=256, 51-bit
     limbs, base 2^17, depth <= 12) as the chain those schemes run per level: preimage of a 2d-column target,
@@ -712,16 +733,57 @@ class M4(Workload):
         assert self.mx.GpuDCRTPolyMatrix.gadget_matrix(self.params, self.dd) * self.mmat.decompose() == self.mmat
 
 
+class M4Batched(M4):
+    """The same chain with the requests a GGH15 caller actually holds at once (src/lookup/ggh15/pubkey_gpu.rs:615-971 hands
+    `preimage_batched_sharded` dozens of targets per key): `requests` independent 4-column targets against one trapdoor per
+    step, through `preimage_many` (one sequence of launches over the concatenated targets, every request's output identical
+    to what it gets alone), then the requests' encoding products and mul_decompose gates as one `gpupoly_batch` level."""
+
+    name = "m4_batched"
+    requests = 16
+
+    def setup(self):
+        super().setup()
+        mx, p = self.mx, self.params
+        us = mx.GpuDCRTPolyUniformSampler()
+        self.targets = [self.target] + [us.sample_uniform(p, self.dd, 2 * self.dd, mx.DistType.FinRingDist()) for _ in range(self.requests - 1)]
+        self.units = 2 * self.dd * self.requests * self.d.world
+        self.desc = (f"M4 batched: {self.requests} requests per step, each = preimage of {2 * self.dd} columns + (1x{self.a0.col_size()})*K "
+                     f"+ mul_decompose; n=256, L={self.depth} (51-bit, u64 words), base 2^17, d={self.dd}; preimage_many + one gpupoly_batch level")
+
+    def step(self, i, mark):
+        from mxx_amd import _ffi
+
+        if mark:
+            self.mark(i, 0)
+        n0 = _ffi.lib().gpupoly_launch_count()
+        self.ks = self.sampler.preimage_many(self.params, self.td0, self.a0, self.targets)
+        gates = [("mul", self.c0, k_) for k_ in self.ks] + [("mul_decompose", self.bmat, self.mmat)] * self.requests
+        outs = self.mx.GpuDCRTPolyMatrix.eval_gates(gates)
+        self.c1s, self.mds = outs[: self.requests], outs[self.requests:]
+        self.k, self.md = self.ks[0], self.mds[0]
+        self.launches_per_step = _ffi.lib().gpupoly_launch_count() - n0
+        if mark:
+            self.mark(i, 1)
+
+    def check(self):
+        for k_, t in zip(self.ks, self.targets):
+            assert self.a0 * k_ == t, "A*x != u"
+        assert self.c1s[3] == self.c0 * self.ks[3] and self.mds[5] == self.bmat.mul_decompose(self.mmat)
+
+
 WORKLOADS = {"m1": M1, "m2a": M2A, "m2b": M2B, "m2b_decompose": M2BDecompose, "m2b_mul_decompose": M2BMulDecompose,
-             "m3a": M3A, "m3b": M3B, "m4": M4}
+             "m3a": M3A, "m3b": M3B, "m3a_refseq": M3ARefSeq, "m4": M4, "m4_batched": M4Batched}
 
 
 # ---------------------------------------------------------------------------------------------------
 # measurement
 # ---------------------------------------------------------------------------------------------------
-def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
+def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int, sustain_s: float = 0.0):
     """The contract's timed region (K steps, barrier + synchronise on both sides, MAX over ranks), then
-    `repeats` more repetitions of the same K steps for median / min."""
+    `repeats` more repetitions of the same K steps for median / min, then - `sustain_s` > 0, the headline workload - ONE
+    contiguous region of about that many seconds of the same steps (K steps of a sub-millisecond product last 12 ms, too
+    short for an outside utilisation sampler to ever see the device busy; VERDICT r4 weak #2)."""
     mx = wl.mx
     for i in range(steps):  # create every hipEvent before the timed region (creation on the host would be timed)
         for j in range(wl.nmarks):
@@ -752,6 +814,18 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
         wl.drain()
         d.barrier_sync(mx.gpu_device_sync)
         reps.append(d.max_over_ranks(time.perf_counter() - t1) * 1e3 / steps)
+    sustained = None
+    if sustain_s > 0.0:
+        count = max(steps, int(sustain_s / max(statistics.median([elapsed / steps] + [r * 1e-3 for r in reps]), 1e-6)))
+        count = int(d.max_over_ranks(float(count)))  # the same number of steps (and gathers) on every rank
+        d.barrier_sync(mx.gpu_device_sync)
+        t1 = time.perf_counter()
+        for i in range(count):
+            wl.step(i, False)
+        wl.drain()
+        d.barrier_sync(mx.gpu_device_sync)
+        dt = d.max_over_ranks(time.perf_counter() - t1)
+        sustained = {"steps": count, "seconds": dt, "ms_per_step": dt * 1e3 / count, "value": wl.units * count / dt}
     other = None
     if wl.gather is not None and hasattr(wl, "lazy_gather"):
         # the same K steps under the other exchange policy (per step <-> once per region), so that the line shows what the
@@ -775,7 +849,7 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
     failure = None
     try:
         wl.check()
-    except AssertionError as e:
+    except Exception as e:  # noqa: BLE001 - any failure (a GpuPolyError, an allocation) must still reach the collective below
         failure = e
     all_ok = d.min_over_ranks(0.0 if failure else 1.0)
     if failure is not None:
@@ -785,6 +859,7 @@ def run_block(wl: Workload, d: Dist, steps: int, warmup: int, repeats: int):
     all_ms = [elapsed * 1e3 / steps] + reps
     return {
         "other_gather": other,
+        "sustained": sustained,
         "elapsed_s": elapsed,
         "ms_per_step": elapsed * 1e3 / steps,
         "value": wl.units * steps / elapsed,
@@ -807,16 +882,22 @@ def roofline_of(wl: Workload, kernel_ms):
     achieved = algo / (ms * 1e-3) / 1e9
     traffic = source = None
     # PMC counters need their own rocprofv3 passes (the guide's HBM section): the figure is read from the committed record
-    # of the same command (tools/collect_r04.sh -> tools/pmc_window.py: only the launches between bench.py's region markers
-    # are counted, FETCH_SIZE doubled as the guide prescribes for gfx950), not measured in this run
-    rec = load_profile_json(f"r04_pmc_{wl.name}.json") if wl.d.world == 1 else None
+    # of the same command (tools/collect_r05.sh -> tools/pmc_window.py: only the launches between bench.py's region markers
+    # are counted, FETCH_SIZE doubled as the guide prescribes for gfx950), not measured in this run - and only while the
+    # record's ISA hash of the kernel equals the hash of the kernel in the library loaded now (load_counters)
+    rec = load_counters(wl.name) if wl.d.world == 1 else None
     krec = (rec or {}).get("kernels", {}).get(kernel_base(label))
-    if krec and krec.get("hbm_bytes_per_launch"):
-        traffic = krec["hbm_bytes_per_launch"]
-        source = f"profiles/r04_pmc_{wl.name}.json ({rec.get('source', 'rocprofv3 --pmc passes')}; kernel {kernel_base(label)}, " \
-                 f"{krec.get('launches_per_step')} launch(es) per step)"
+    stale = None
+    if krec is not None:
+        stale = bool(krec["stale"])
+        if not stale and krec.get("hbm_bytes_per_launch"):
+            traffic = krec["hbm_bytes_per_launch"]
+            source = f"{rec['file']} (head {rec.get('head')}, kernel {kernel_base(label)} isa {krec.get('isa_hash')}: " \
+                     f"{rec.get('source', 'rocprofv3 --pmc passes')}; {krec.get('launches_per_step')} launch(es) per step)"
+        elif stale:
+            source = f"{rec['file']} was counted on another build of {kernel_base(label)} (isa {krec.get('isa_hash')}): not used"
     return {"bound": "hbm", "kernel": label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source, "counters_stale": stale,
             "algorithmic_bytes_per_launch": algo, "kernel_ms": round(ms, 5)}
 
 
@@ -875,27 +956,67 @@ def load_profile_json(name):
         return None
 
 
+def load_counters(workload: str, current_hashes=None):
+    """profiles/pmc_<workload>.json (tools/pmc_window.py) with a verdict per kernel: `stale` = the record was counted on a
+    build whose ISA text of that kernel differs from the library's today (or carries no hash at all, as round 4's files) -
+    its instruction counts and traffic are then NOT used.  None if there is no record."""
+    for name in (f"pmc_{workload}.json", f"r04_pmc_{workload}.json"):
+        rec = load_profile_json(name)
+        if rec is not None:
+            break
+    else:
+        return None
+    if current_hashes is None:
+        from mxx_amd import codeobj
+
+        current_hashes = codeobj.kernel_isa_hashes()
+    rec["file"] = f"profiles/{name}"
+    for base, k in (rec.get("kernels") or {}).items():
+        k["stale"] = k.get("isa_hash") is None or k["isa_hash"] != current_hashes.get(base)
+    rec["stale_kernels"] = sorted(b for b, k in (rec.get("kernels") or {}).items() if k["stale"])
+    return rec
+
+
+def load_valu_mix(current_hashes=None):
+    """{kernel: cycles per VALU instruction} from profiles/valu_mix.json (tools/valu_mix.py), entries of other builds dropped"""
+    rec = load_profile_json("valu_mix.json")
+    if rec is None:
+        return {}
+    if current_hashes is None:
+        from mxx_amd import codeobj
+
+        current_hashes = codeobj.kernel_isa_hashes()
+    return {b: k for b, k in (rec.get("kernels") or {}).items() if k.get("isa_hash") and k["isa_hash"] == current_hashes.get(b)}
+
+
 def composed_roofline(wl: Workload, call_ms: float, steps: int = 3):
     """roofline of a call that is a SEQUENCE of kernels: per kernel the larger of its HBM byte floor (stated algorithmic
     bytes of its operands at the 8 TB/s peak) and its VALU issue floor (wave-level VALU instructions, counted by a committed
     rocprofv3 --pmc SQ_INSTS_VALU pass of this workload, at the ISA mix's cycles per instruction on 1024 SIMDs at 2.4 GHz);
     frac = sum of the floors / the untraced call time.  Durations per kernel are measured HERE with hipEvents."""
     agg = traced_kernels(wl, steps)
-    pmc = load_profile_json(f"r04_pmc_{wl.name}.json") or {}
-    mix = (load_profile_json("r04_valu_mix.json") or {}).get("kernels", {})
+    pmc = load_counters(wl.name) or {}
+    mix = load_valu_mix()
     pk = pmc.get("kernels", {})
-    rows, floor_sum, byte_sum, byte_floor_sum, traced_ms = [], 0.0, 0.0, 0.0, 0.0
+    rows, floor_sum, useful_sum, byte_sum, byte_floor_sum, traced_ms, stale = [], 0.0, 0.0, 0.0, 0.0, 0.0, []
     for base, a in agg.items():
         byte_ms = a["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3
         rec = pk.get(base)
-        valu = issue_ms = price = None
-        if rec and rec.get("launches_per_step"):
+        valu = issue_ms = price = lanes = None
+        if rec and rec["stale"]:
+            stale.append(base)
+        elif rec and rec.get("launches_per_step"):
             # the counted step and the traced step launch the same kernels; scale if the launch counts differ (other column count)
             valu = rec["SQ_INSTS_VALU"] * (a["launches"] / rec["launches_per_step"])
             price = (mix.get(base) or {}).get("cycles_per_inst", DEFAULT_VALU_CYCLES)
             issue_ms = valu * price / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+            lanes = rec.get("lane_utilisation")
         floor = max(byte_ms, issue_ms or 0.0)
+        # the issue floor prices the kernel's OWN executed instructions; lanes masked off inside them did no work, so the
+        # useful part of an issue-bound floor is its lane-utilised share (never below the byte floor)
+        useful = max(byte_ms, (issue_ms or 0.0) * (lanes if lanes is not None else 1.0))
         floor_sum += floor
+        useful_sum += useful
         byte_sum += a["bytes"]
         byte_floor_sum += byte_ms
         traced_ms += a["ms"]
@@ -903,15 +1024,26 @@ def composed_roofline(wl: Workload, call_ms: float, steps: int = 3):
                      "algorithmic_bytes": a["bytes"] or None, "byte_floor_ms": round(byte_ms, 4),
                      "SQ_INSTS_VALU": round(valu) if valu else None, "cycles_per_inst": price,
                      "issue_floor_ms": round(issue_ms, 4) if issue_ms is not None else None,
+                     "lane_utilisation": lanes,
                      "bound": "valu" if (issue_ms or 0.0) > byte_ms else "hbm",
                      "frac": round(floor / a["ms"], 4) if a["ms"] > 0 else None})
     rows.sort(key=lambda r_: -r_["ms"])
     achieved = byte_sum / (call_ms * 1e-3) / 1e9
+    have_lanes = any(r_["lane_utilisation"] is not None for r_ in rows)
+    weighted = sum((r_["issue_floor_ms"] or 0.0) for r_ in rows if r_["lane_utilisation"] is not None)
+    fresh = bool(pk) and not stale
     return {"bound": "composed: per kernel max(HBM byte floor at 8 TB/s, VALU issue floor at the ISA mix's price on 1024 SIMDs x 2.4 GHz)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(floor_sum / call_ms, 4), "frac_hbm_bytes_only": round(byte_floor_sum / call_ms, 4),
-            "traffic": pmc.get("hbm_bytes_per_step"),
-            "traffic_source": pmc.get("source"),
+            # frac prices the instructions the kernels EXECUTE; frac_useful discounts the issue-bound floors by the counted
+            # active-lane share of those instructions (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) per kernel)
+            "frac_useful": round(useful_sum / call_ms, 4) if have_lanes else None,
+            "lane_utilisation": round(sum((r_["issue_floor_ms"] or 0.0) * r_["lane_utilisation"] for r_ in rows
+                                          if r_["lane_utilisation"] is not None) / weighted, 4) if have_lanes and weighted > 0 else None,
+            "counters_stale": (not fresh) if pk else None, "stale_kernels": stale,
+            "counters_head": pmc.get("head"), "counters_file": pmc.get("file"),
+            "traffic": pmc.get("hbm_bytes_per_step") if fresh else None,
+            "traffic_source": pmc.get("source") if fresh else None,
             "algorithmic_bytes_per_call": byte_sum, "call_ms": round(call_ms, 4),
             "sum_of_kernel_ms_traced": round(traced_ms, 4), "sum_of_floors_ms": round(floor_sum, 4),
             "valu_counts_source": pmc.get("source") if pk else None,
@@ -941,6 +1073,7 @@ def block_json(wl: Workload, res, d: Dist, args, steps, warmup):
         "config": {"workload": wl.desc, "ring_dim": wl.params.ring_dimension(), "limbs": wl.depth,
                    "limb_bits": 24 if wl.word == 4 else 51, "units_per_step": wl.units, "sharding": wl.sharding},
         "repeats": res["repeats"],
+        **({"sustained": res["sustained"]} if res.get("sustained") else {}),
         "roofline": roofline_of(wl, res["kernel_ms"]),
         **({"kernel_launches_per_step": int(wl.launches_per_step)} if hasattr(wl, "launches_per_step") else {}),
         **({"exchange": torch_exchange_report(wl, d)} if d.active and not d.inproc and getattr(wl, "strong", False)
@@ -958,12 +1091,14 @@ def kernels_block(m1: Workload, res):
     (fl, fa), (gl, ga) = m1.kernels
     out["ntt_forward"] = entry(fl, res["kernel_ms"][0], fa)
     out["mul_intt_fused"] = entry(gl, res["kernel_ms"][1], ga)
-    rec = load_profile_json("r04_pmc_m1.json") if m1.d.world == 1 else None
+    rec = load_counters("m1") if m1.d.world == 1 else None
     for key, base in (("ntt_forward", "ntt14::fwd_kernel"), ("mul_intt_fused", "ntt14::inv_kernel")):
         krec = (rec or {}).get("kernels", {}).get(base)
-        if krec and krec.get("hbm_bytes_per_launch"):  # counted HBM bytes per launch (committed rocprofv3 --pmc passes of `--workload m1`)
+        if krec is not None:
+            out[key]["counters_stale"] = bool(krec["stale"])
+        if krec and not krec["stale"] and krec.get("hbm_bytes_per_launch"):  # counted HBM bytes per launch (committed rocprofv3 --pmc passes of `--workload m1`)
             out[key]["traffic"] = krec["hbm_bytes_per_launch"]
-            out[key]["traffic_source"] = "profiles/r04_pmc_m1.json"
+            out[key]["traffic_source"] = f"{rec['file']} (head {rec.get('head')})"
             if krec.get("SQ_WAIT_ANY") and krec.get("SQ_WAVE_CYCLES"):
                 out[key]["SQ_WAIT_ANY_over_SQ_WAVE_CYCLES"] = round(krec["SQ_WAIT_ANY"] / krec["SQ_WAVE_CYCLES"], 3)
     mul_ms, inv_ms = m1.standalone_kernels()
@@ -1135,6 +1270,249 @@ def main_inproc(args, emit):
     emit(line)
 
 
+# ---------------------------------------------------------------------------------------------------
+# SURVEY 8 rows f1 (compact wire format) and f4 (gate batching) as driver-visible figures
+# ---------------------------------------------------------------------------------------------------
+def compact_bytes_block(mx, x, reps=5):
+    """ABI-only store / load of a preimage (`gpu_matrix_store_compact_bytes` / `gpu_matrix_load_compact_bytes`,
+    src/matrix/gpu_dcrt_poly.rs:956-1044 are their callers) into / from PINNED host memory: payload bytes, the device
+    kernels' time from the library's launch trace against their HBM floor, and what is left of the synchronous call -
+    the device-to-host copy - against PCIe.  `x` = an EVAL matrix (the M3A preimage); the store takes it to the
+    coefficient domain in place, as the reference's does (MatrixSerde.cu:1108-1118), so every repetition starts from a clone."""
+    import ctypes as C
+
+    from mxx_amd import _ffi
+
+    lib = _ffi.lib()
+    p = x.params
+    n, L = p.ring_dimension(), x.level + 1
+    coeffs = x.nrow * x.ncol * n
+    cap = (coeffs * sum(q.bit_length() for q in p.moduli()[:L]) + 7) // 8
+    word = p.ctx().word_bytes()
+    host = lib.gpu_pinned_alloc(cap)
+    if not host:
+        raise RuntimeError("compact_bytes_block: gpu_pinned_alloc failed")
+    try:
+        buf = C.cast(host, C.POINTER(C.c_uint8))
+        bits, bpc, plen = C.c_uint16(0), C.c_uint16(0), C.c_size_t(0)
+        store_ms, load_ms, kern_store, kern_load, rows = [], [], [], [], None
+        for rep in range(reps + 1):
+            m = x.clone()
+            mx.gpu_device_sync()
+            _ffi.trace_begin()
+            t0 = time.perf_counter()
+            _ffi.check_status(lib.gpu_matrix_store_compact_bytes(m.raw, buf, cap, C.byref(bits), C.byref(bpc), C.byref(plen)), "gpu_matrix_store_compact_bytes")
+            dt = time.perf_counter() - t0
+            ent = _ffi.trace_end()
+            back = mx.GpuDCRTPolyMatrix(p, x.nrow, x.ncol, x.level, False)
+            mx.gpu_device_sync()
+            _ffi.trace_begin()
+            t1 = time.perf_counter()
+            _ffi.check_status(lib.gpu_matrix_load_compact_bytes(back.raw, buf, plen.value, bits.value), "gpu_matrix_load_compact_bytes")
+            mx.gpu_device_sync()
+            dl = time.perf_counter() - t1
+            lent = _ffi.trace_end()
+            if rep:  # the first repetition warms the kernels and the allocator
+                store_ms.append(dt * 1e3)
+                load_ms.append(dl * 1e3)
+                kern_store.append(sum(e["ms"] for e in ent))
+                kern_load.append(sum(e["ms"] for e in lent))
+                rows = [{"kernel": kernel_base(e["kernel"]), "ms": round(e["ms"], 4)} for e in ent]
+        m.is_ntt = False
+        back.is_ntt = False
+        assert back == m, "compact bytes: load(store(x)) != x"
+    finally:
+        lib.gpu_pinned_free(host)
+    payload = plen.value
+    s_ms, l_ms, ks, kl = (statistics.median(v) for v in (store_ms, load_ms, kern_store, kern_load))
+    mat_bytes = float(x.nrow * x.ncol * L * n * word)
+    # store: inverse transform (read + write), width pass (read), pack pass (read) + payload zeroed and written
+    algo_store = 4.0 * mat_bytes + 2.0 * payload
+    floor_ms = algo_store / (HBM_PEAK_GBS * 1e9) * 1e3
+    d2h = max(s_ms - ks, 1e-6)
+    return {"metric": "compact_store_payload_bytes_per_s", "value": payload / (s_ms * 1e-3), "unit": "B/s", "ms_per_step": s_ms,
+            "config": {"workload": f"compact wire format of the M3A preimage ({x.nrow}x{x.ncol}, n=2^14, L={L}, EVAL in): ABI-only store "
+                                   "into pinned host memory, then load back; no host-mirror framing"},
+            "payload_bytes": payload, "max_coeff_bits": bits.value, "kernel_ms": ks, "d2h_ms": d2h,
+            "pcie_GBps": payload / (d2h * 1e-3) / 1e9, "host_ms": 0.0,
+            "load_ms": l_ms, "load_kernel_ms": kl, "store_kernels": rows,
+            "roofline": {"bound": "hbm", "frac": round(floor_ms / ks, 4) if ks > 0 else None,
+                         "algorithmic_bytes_per_call": algo_store, "byte_floor_ms": round(floor_ms, 4), "kernel_ms": round(ks, 4),
+                         "note": "frac = HBM floor of the store's device kernels (INTT r+w, width pass r, pack pass r, payload "
+                                 "memset + w) / their traced time; the call itself is bound by the D2H copy (pcie_GBps)"}}
+
+
+def gate_batch_block(mx, device, count=16, reps=20):
+    """one level of independent circuit gates as ONE call (`gpupoly_matrix_mul_batch`) against the loop
+    of `gpu_matrix_mul` calls src/circuit/poly_circuit/eval.rs:269 issues, on the M4 ring (n=256, 12 x 51-bit limbs):
+    `count` products (1x76)*(76x4)."""
+    p = mx.GpuDCRTPolyParams(256, mx.gen_crt_basis(256, 12, 51), 17, gpu_ids=[device])
+    ctx = p.ctx()
+    us = mx.GpuDCRTPolyUniformSampler()
+    ls = [us.sample_uniform(p, 1, 76, mx.DistType.FinRingDist()) for _ in range(count)]
+    rs = [us.sample_uniform(p, 76, 4, mx.DistType.FinRingDist()) for _ in range(count)]
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(reps):
+            mx.gpu_device_sync()
+            t0 = time.perf_counter()
+            out = fn()
+            mx.gpu_device_sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return statistics.median(ts), out
+
+    loop_ms, loop_out = timed(lambda: [l_ * r_ for l_, r_ in zip(ls, rs)])
+    batch_ms, batch_out = timed(lambda: mx.GpuDCRTPolyMatrix.mul_batch(ls, rs))
+    assert all(a == b for a, b in zip(loop_out, batch_out)), "gate batch: batched products differ from the loop's"
+    algo = count * float(1 * 76 + 76 * 4 + 1 * 4) * 256 * 12 * ctx.word_bytes()
+    return {"metric": "gate_products_per_s", "value": count / (batch_ms * 1e-3), "unit": "products/s", "ms_per_step": batch_ms,
+            "config": {"workload": f"{count} independent products (1x76)*(76x4), n=256, L=12 (51-bit): gpupoly_matrix_mul_batch (one "
+                                   "call) against a loop of gpu_matrix_mul"},
+            "loop_ms": loop_ms, "speedup_vs_loop": loop_ms / batch_ms,
+            "roofline": {"bound": "hbm", "frac": round(algo / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_call": algo,
+                         "note": "launch- and latency-bound: 12 MB of operands"}}
+
+
+# ---------------------------------------------------------------------------------------------------
+# the short line (what the driver parses) built from the full record
+# ---------------------------------------------------------------------------------------------------
+SHORT_LINE_LIMIT = 4000  # bytes; the driver keeps an 8 KB tail of stdout (round 4's 30 KB line could not be parsed)
+
+
+def sig(x, digits=5):
+    """float rounded to `digits` significant digits (ints, None and strings pass through)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x == 0.0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    from math import floor, log10
+
+    r = round(x, digits - 1 - int(floor(log10(abs(x)))))
+    return int(r) if abs(r) >= 10 ** digits else r
+
+
+def _cpu_short(cb):
+    if not cb:
+        return None
+    out = {"value": sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind", "port"),
+           "label": "CPU restatement (oracle/, not OpenFHE)", "sample": (cb.get("sample") or "")[:96]}
+    one = cb.get("one_core") or {}
+    if one.get("value") is not None:
+        out["one_core_value"] = sig(one["value"])
+    return out
+
+
+def _config_record(blk):
+    """ONE short record of a block of the full line: time, throughput, roofline fractions, CPU figure"""
+    if not blk:
+        return None
+    rf = blk.get("roofline") or {}
+    cb = blk.get("cpu_baseline") or {}
+    rec = {"ms_per_step": sig(blk.get("ms_per_step")), "value": sig(blk.get("value")), "unit": blk.get("unit"),
+           "frac": rf.get("frac")}
+    for key in ("frac_hbm_bytes_only", "frac_useful", "lane_utilisation", "counters_stale"):
+        if rf.get(key) is not None:
+            rec[key] = rf[key]
+    if rf.get("traffic") and (rf.get("algorithmic_bytes_per_call") or rf.get("algorithmic_bytes_per_launch")):
+        rec["traffic_over_algorithmic"] = sig(rf["traffic"] / (rf.get("algorithmic_bytes_per_call") or rf["algorithmic_bytes_per_launch"]), 4)
+    if blk.get("kernel_launches_per_step") is not None:
+        rec["launches_per_step"] = blk["kernel_launches_per_step"]
+    for key in ("requests_in_flight", "speedup_vs_one_request", "payload_bytes", "kernel_ms", "d2h_ms", "pcie_GBps", "host_ms",
+                "speedup_vs_loop", "loop_ms", "vs_extension_sequence"):
+        if blk.get(key) is not None:
+            rec[key] = sig(blk[key])
+    if cb.get("value") is not None:
+        rec["cpu_value"], rec["cpu_cores"] = sig(cb["value"]), cb.get("cores")
+    return rec
+
+
+def short_line(full):
+    """The driver-facing line: the contract's keys for the headline workload (M2A), its roofline and CPU baseline, and a flat
+    `configs` map with one short record per BASELINE configuration.  Everything else stays in bench_detail.json."""
+    if "metric" not in full:
+        return full  # --dry-run and the like
+    rf = full.get("roofline") or {}
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = sig(line["value"], 7), sig(line["ms_per_step"], 6)
+    line["config"] = {"workload": (cfg.get("workload") or "")[:140], "units_per_step": cfg.get("units_per_step"),
+                      "sharding": (cfg.get("sharding") or "")[:100]}
+    if full.get("gather") is not None:
+        line["gather"] = full["gather"]
+    rep = full.get("repeats") or {}
+    if rep:
+        line["median_ms_per_step"] = sig(rep.get("median_ms_per_step"), 6)
+    if full.get("sustained"):
+        line["sustained"] = {k: sig(v) for k, v in full["sustained"].items() if k in ("steps", "seconds", "ms_per_step")}
+    line["roofline"] = {"bound": rf.get("bound") if rf.get("bound") in ("hbm", "mfma") else "hbm",
+                        "kernel": (rf.get("kernel") or "")[:72], "achieved": rf.get("achieved"), "peak": rf.get("peak"),
+                        "unit": rf.get("unit"), "frac": rf.get("frac"), "traffic": rf.get("traffic"),
+                        "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"), "kernel_ms": rf.get("kernel_ms")}
+    if rf.get("counters_stale") is not None:
+        line["roofline"]["counters_stale"] = rf["counters_stale"]
+    line["cpu_baseline"] = _cpu_short(full.get("cpu_baseline"))
+    configs = {}
+    k = full.get("kernels")
+    if k:
+        rec = {"ms_per_step": sig(k.get("step_ms")), "value": sig(k.get("ring_mults_per_s")), "unit": "ring-ops/s"}
+        for key, short in (("ntt_forward", "ntt"), ("ntt_inverse", "intt"), ("mod_mul", "mul"), ("mul_intt_fused", "mul_intt")):
+            e = k.get(key)
+            if e:
+                rec[short + "_us"], rec[short + "_frac"] = e.get("us"), e.get("frac_of_hbm_peak")
+        lb = (k.get("large_batch") or {}).get("ntt_forward")
+        if lb:
+            rec["ntt_frac_beyond_cache"] = lb.get("frac_of_hbm_peak")
+        cb = k.get("cpu_baseline") or {}
+        if cb.get("value") is not None:
+            rec["cpu_value"], rec["cpu_cores"] = sig(cb["value"]), cb.get("cores")
+        configs["m1_ntt_mul"] = rec
+    m2b = full.get("m2b")
+    if m2b:
+        configs["m2b_product"] = _config_record(m2b)
+        if (m2b.get("roofline") or {}).get("frac_mac_floor") is not None:
+            configs["m2b_product"]["frac_mac_floor"] = m2b["roofline"]["frac_mac_floor"]
+        configs["m2b_decompose"] = _config_record(m2b.get("decompose"))
+        configs["m2b_mul_decompose"] = _config_record(m2b.get("mul_decompose"))
+    for key, name in (("preimage", "m3a_preimage"), ("preimage_reference_sequence", "m3a_reference_sequence"),
+                      ("preimage_m3b", "m3b_preimage"), ("chain_m4", "m4_chain"), ("chain_m4_batched", "m4_chain_batched"),
+                      ("compact_bytes", "compact_bytes"), ("gate_batch", "gate_batch")):
+        if full.get(key):
+            configs[name] = _config_record(full[key])
+    s8 = (full.get("preimage") or {}).get("shard_of_8")
+    if s8 and configs.get("m3a_preimage"):
+        configs["m3a_preimage"]["predicted_strong_eff_at_8"] = s8.get("predicted_strong_scaling_efficiency_at_8")
+    iu = full.get("independent_units")
+    if iu:
+        line["independent_units"] = {"value": sig(iu.get("value")), "ms_per_step": sig(iu.get("ms_per_step")), "scaling": "weak"}
+    piu = (full.get("preimage") or {}).get("independent_units")
+    if piu and configs.get("m3a_preimage"):
+        configs["m3a_preimage"]["independent_units_value"] = sig(piu.get("value"))
+    line["configs"] = {name: rec for name, rec in configs.items() if rec}
+    ex = full.get("exchange") or (full.get("preimage") or {}).get("exchange")
+    if ex:
+        line["exchange"] = {k_: ex.get(k_) for k_ in ("ranks_seen", "comm_backend", "self_validated", "distinct_devices",
+                                                      "comm_verified_by_this_run")}
+        pex = (full.get("preimage") or {}).get("exchange")
+        if pex and pex is not ex:
+            line["exchange"]["preimage_self_validated"] = pex.get("self_validated")
+    line["detail"] = "bench_detail.json (also on stderr)"
+    # never exceed the limit: drop the optional parts, least important first
+    for victim in ("detail", "sustained", "independent_units"):
+        if len(json.dumps(line)) <= SHORT_LINE_LIMIT:
+            break
+        line.pop(victim, None)
+    for name in list(line.get("configs", {})):
+        if len(json.dumps(line)) <= SHORT_LINE_LIMIT:
+            break
+        rec = line["configs"][name]
+        line["configs"][name] = {k_: rec[k_] for k_ in ("ms_per_step", "value", "unit", "frac") if k_ in rec}
+    return line
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inproc:
@@ -1147,7 +1525,20 @@ def main():
     os.dup2(2, 1)
 
     def emit(obj):
-        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+        """stdout gets ONE short JSON line (< 4 KB: the driver keeps an 8 KB tail of stdout and parses its last line); the
+        full record - per-kernel tables, sources, repeats - goes to bench_detail.json next to this file (and under
+        gpurun_out/ when that exists, so that it travels back from a GPU box) and to stderr."""
+        detail = json.dumps(obj)
+        for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+            try:
+                if os.path.isdir(os.path.dirname(path)):
+                    with open(path, "w") as f:
+                        f.write(detail + "\n")
+            except OSError as e:
+                print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+        print("bench.py detail: " + detail, file=sys.stderr)
+        sys.stderr.flush()
+        os.write(json_fd, (json.dumps(short_line(obj)) + "\n").encode())
 
     if args.inproc and "WORLD_SIZE" not in os.environ:
         return main_inproc(args, emit)
@@ -1176,10 +1567,10 @@ def main():
         device = d.local_rank % mx.detected_gpu_device_count()
     steps, warmup = args.steps, args.warmup
 
-    def run(name, steps_, warmup_, repeats_):
+    def run(name, steps_, warmup_, repeats_, sustain_s=0.0):
         wl = WORKLOADS[name](mx, d, args, device)
         wl.setup()
-        res = run_block(wl, d, steps_, warmup_, repeats_)
+        res = run_block(wl, d, steps_, warmup_, repeats_, sustain_s)
         return wl, res
 
     def independent_units(name):
@@ -1211,7 +1602,7 @@ def main():
         return w, r, blk
 
     if args.workload == "default":
-        wl, res = run("m2a", steps, warmup, args.repeats)
+        wl, res = run("m2a", steps, warmup, args.repeats, args.sustain)
         line = block_json(wl, res, d, args, steps, warmup)
         line["output_buffers"] = ("the product writes into pre-allocated output matrices; the reference's timed `&left * &right` "
                                   "also creates its output (src/matrix/gpu_dcrt_poly.rs:1792-1815) - microseconds from the stream-ordered cache")
@@ -1240,7 +1631,15 @@ def main():
             pre["shard_of_8"] = {"columns": 7, "call_ms": round(ms7, 4), "linear_share_ms": round(pre_res["kernel_ms"][0] * 7 / 50, 4),
                                  "predicted_strong_scaling_efficiency_at_8": round(pre_res["kernel_ms"][0] / (8 * ms7), 3)}
         line["preimage"] = pre
+        if d.world == 1:
+            line["compact_bytes"] = compact_bytes_block(mx, pre_wl.x)
         del pre_wl
+        if d.world == 1:
+            w_ref, r_ref, ref = sub_block("m3a_refseq", max(5, steps // 2), 2, composed=False, cpu=False)
+            del w_ref
+            ref.pop("scaling", None)
+            ref["vs_extension_sequence"] = ref["ms_per_step"] / pre["ms_per_step"]
+            line["preimage_reference_sequence"] = ref
         m1, m1_res = run("m1", steps, warmup, 0)
         line["kernels"] = kernels_block(m1, m1_res)
         del m1
@@ -1264,19 +1663,27 @@ def main():
         w4, r4, m4 = sub_block("m4", steps, min(args.repeats, 3))
         del w4
         line["chain_m4"] = m4
+        w4b, r4b, m4b = sub_block("m4_batched", steps, min(args.repeats, 3), cpu=False)
+        del w4b
+        m4b["requests_in_flight"] = M4Batched.requests
+        m4b["speedup_vs_one_request"] = m4b["value"] / m4["value"]
+        line["chain_m4_batched"] = m4b
+        if d.world == 1:
+            line["gate_batch"] = gate_batch_block(mx, device)
         line["baseline_configs"] = {
             "configs[0] (plumbing, n=2^12, L=2, 4x4)": "CPU-runnable parity case: tests/test_gpu_surface.py + tests/test_oracle.py, not a bench line",
             "configs[1] (NTT / INTT / mod-mul, n=2^14, L=4, 1024 polys)": "kernels",
             "configs[2] (64x64 product + gadget decompose, n=2^14, L=8)": "m2b (product), m2b.decompose, m2b.mul_decompose",
             "configs[3] (bench_preimage shape, L=8)": "preimage_m3b (the reference bench's own L=10 shape: preimage)",
-            "configs[4] (GGH15 mod-p chain parameters, n=256, 51-bit limbs)": "chain_m4",
+            "configs[4] (GGH15 mod-p chain parameters, n=256, 51-bit limbs)": "chain_m4 (one request at a time), chain_m4_batched (16 requests per call)",
+            "SURVEY 8 f1 / f4 and the reference's own preimage call sequence": "compact_bytes, gate_batch, preimage_reference_sequence",
             "benches/bench_matrix_mul_gpu.rs shape (the metric's own)": "top level (M2A)"}
         if d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:  # an N = 1 leg: the other ranks would wait for it
             line["cpu_baseline"] = cpu_baseline("m2a", args.cpu_seconds)
             line["preimage"]["cpu_baseline"] = cpu_baseline("m3a", args.cpu_seconds)
             line["kernels"]["cpu_baseline"] = cpu_baseline("m1", args.cpu_seconds / 2)
     else:
-        wl, res = run(args.workload, steps, warmup, args.repeats)
+        wl, res = run(args.workload, steps, warmup, args.repeats, args.sustain if args.workload == "m2a" else 0.0)
         line = block_json(wl, res, d, args, steps, warmup)
         if args.workload == "m1":
             line["kernels"] = kernels_block(wl, res)
@@ -1320,9 +1727,9 @@ def cpu_baseline(wl: str, budget_s: float):
     O.use_native_build()  # -O3 -march=native -fopenmp for this host, in a temp dir
     lib = O.lib()
     cores = host_cores()
-    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m2b_decompose": 8, "m2b_mul_decompose": 8, "m3a": 10, "m3b": 8, "m4": 12}[wl]
-    n = 256 if wl == "m4" else N_RING
-    moduli = O.gen_crt_basis(n, depth, 51 if wl == "m4" else 24)
+    depth = {"m1": 4, "m2a": 15, "m2b": 8, "m2b_decompose": 8, "m2b_mul_decompose": 8, "m3a": 10, "m3b": 8, "m3a_refseq": 10, "m4": 12, "m4_batched": 12}[wl]
+    n = 256 if wl.startswith("m4") else N_RING
+    moduli = O.gen_crt_basis(n, depth, 51 if wl.startswith("m4") else 24)
     mod = np.asarray(moduli, dtype=np.uint64)
     mp = mod.ctypes.data_as(C.POINTER(C.c_uint64))
     dp = C.POINTER(C.c_double)
@@ -1406,7 +1813,7 @@ def cpu_baseline_preimage(O, wl, n, moduli, cores, budget_s, out):
     factors prepared outside, as on the GPU; the kernels are C/OpenMP, Python only sequences them."""
     import numpy as np
 
-    base, sigma = (17, 4.578) if wl == "m4" else (12, 4.578)
+    base, sigma = (17, 4.578) if wl.startswith("m4") else (12, 4.578)
     cols = 4
     seed = bytes(range(32))
     O.lib().orc_set_threads(cores)

@@ -261,9 +261,41 @@ const char *gpupoly_comm_backend(const GpuComm *comm); /* "rccl" or "peer" */
  * threads may keep enqueueing work on the contexts' streams meanwhile, as long as nothing enqueued after the call
  * writes a block that was passed to it before the call returns.  The outputs' format tags change only on success. */
 int gpupoly_matrix_all_gather_columns(GpuComm *comm, const GpuMatrix *const *local_blocks, GpuMatrix *const *full);
+/* ---- several independent requests in one launch (replaces the rayon fan-out of small requests,
+ * src/sampler/trapdoor/gpu.rs:371-397, whose callers - src/lookup/ggh15/pubkey_gpu.rs:615-971 - hand it dozens of
+ * few-column targets against one trapdoor).  A matrix is read as the column-wise concatenation of `nseg` segments
+ * (1..64), segment j = the next seg_cols[j] columns, with its own seed seeds[j]; the columns of segment j come out
+ * bit for bit as the plain entry point writes them for a matrix made of those columns alone under seeds[j] (every
+ * element's stream is keyed by its position inside its segment).  Gaussian distribution / trapdoor dimension <= 2 /
+ * at most four digits per tower / n a multiple of 64 (128 for _sample_distribution_segments); anything else returns
+ * an error whose text contains "unsupported" and the caller issues the requests one by one.                      */
+int gpupoly_matrix_sample_distribution_segments(GpuMatrix *out, int dist_type, double sigma, const GpuRngSeed *seeds,
+                                                const size_t *seg_cols, size_t nseg);
+int gpupoly_matrix_sample_p1_full_cached_segments(const GpuP1CovarianceCache *cache, const GpuMatrix *tp2,
+                                                  const GpuRngSeed *seeds, const size_t *seg_cols, size_t nseg,
+                                                  GpuMatrix *out);
+int gpupoly_matrix_gauss_samp_gq_arb_base_segments(GpuMatrix *src, uint32_t base_bits, double c, double dgg_stddev,
+                                                   const GpuRngSeed *seeds, const size_t *seg_cols, size_t nseg,
+                                                   GpuMatrix *out);
+/* out = [blocks[0] | blocks[1] | ...] / blocks[j] = the next blocks[j]->cols columns of src, in one launch per 64
+ * blocks (the wrapper's concat_columns / slice_columns are a gpu_matrix_copy_block launch per block,
+ * src/matrix/gpu_dcrt_poly.rs:1216-1260).  Same rows, level and context everywhere; the written side takes the read
+ * side's format tag.                                                                                              */
+int gpupoly_matrix_concat_columns(GpuMatrix *out, const GpuMatrix *const *blocks, size_t n);
+int gpupoly_matrix_split_columns(const GpuMatrix *src, GpuMatrix *const *blocks, size_t n);
 /* kernel launches issued by the library since it was loaded (every context; copies / memsets not counted): bench.py
  * reports launches per step for the launch-bound small-ring chain                                              */
 uint64_t gpupoly_launch_count(void);
+/* Test instrument: evaluates the samplers' deterministic math (mxx_amd/csrc/detmath.h) ON THE DEVICE for n host-supplied
+ * doubles - fn 0: log(x), 1: cos(2 pi x), 2: sqrt(-2 log x) - and copies the results back (synchronous).  The Box-Muller
+ * step of the G-lattice sampler (cuda/src/matrix/MatrixTrapdoor.cu:701-833 calls log / cos there) is the only place on the
+ * path with transcendental functions; this lets a test hold the device's results to libm (log and sqrt(-2 log) within 2 ulp, cos(2 pi x) within 3). */
+int gpupoly_detmath_eval(GpuContext *ctx, int fn, const double *host_in, double *host_out, size_t n);
+/* 1 if `device` can address `peer`'s memory directly (xGMI peer mapping; a device always reaches itself) */
+int gpupoly_device_can_access_peer(int device, int peer, int *out_can);
+/* a one-thread no-op kernel (`gpupoly_marker_kernel`) on the context's stream: delimits bench.py's timed region in a
+ * profiler's dispatch list (tools/pmc_window.py counts only what lies between two markers)                     */
+int gpupoly_marker_launch(GpuContext *ctx, uint32_t id);
 /* Launch trace (bench.py's composed roofline of a multi-kernel call: a preimage, a chain step).  Between _begin and
  * _end every kernel launch and every device-to-device copy of the library - any context, any host thread - is
  * bracketed by two hipEvents on the stream it is enqueued on.  _end stops recording, waits for the recorded work and
@@ -271,16 +303,6 @@ uint64_t gpupoly_launch_count(void);
  * launch's operands read once + written once, 0 where the launcher does not state them).  The string belongs to the
  * library and stays valid until the next _begin / _end; NULL on error.  Tracing costs two event records per launch:
  * durations are the kernels' own, the call's wall time is not what an untraced call takes.                       */
-/* Test instrument: evaluates the samplers' deterministic math (mxx_amd/csrc/detmath.h) ON THE DEVICE for n host-supplied
- * doubles - fn 0: log(x), 1: cos(2 pi x), 2: sqrt(-2 log x) - and copies the results back (synchronous).  The Box-Muller
- * step of the G-lattice sampler (cuda/src/matrix/MatrixTrapdoor.cu:701-833 calls log / cos there) is the only place on the
- * path with transcendental functions; this lets a test hold the device's results to libm within 2 ulp.           */
-int gpupoly_detmath_eval(GpuContext *ctx, int fn, const double *host_in, double *host_out, size_t n);
-/* 1 if `device` can address `peer`'s memory directly (xGMI peer mapping; a device always reaches itself) */
-int gpupoly_device_can_access_peer(int device, int peer, int *out_can);
-/* a one-thread no-op kernel (`gpupoly_marker_kernel`) on the context's stream: delimits bench.py's timed region in a
- * profiler's dispatch list (tools/pmc_window.py counts only what lies between two markers)                     */
-int gpupoly_marker_launch(GpuContext *ctx, uint32_t id);
 int gpupoly_trace_begin(void);
 const char *gpupoly_trace_end(void);
 const char *gpupoly_version(void);

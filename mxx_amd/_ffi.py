@@ -133,6 +133,11 @@ SIGNATURES = {
     "gpupoly_comm_size": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpupoly_comm_backend": (C.c_char_p, [_vp]),
     "gpupoly_matrix_all_gather_columns": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "gpupoly_matrix_sample_distribution_segments": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(GpuRngSeed), C.POINTER(_sz), _sz]),
+    "gpupoly_matrix_sample_p1_full_cached_segments": (C.c_int, [_vp, _vp, C.POINTER(GpuRngSeed), C.POINTER(_sz), _sz, _vp]),
+    "gpupoly_matrix_gauss_samp_gq_arb_base_segments": (C.c_int, [_vp, C.c_uint32, C.c_double, C.c_double, C.POINTER(GpuRngSeed), C.POINTER(_sz), _sz, _vp]),
+    "gpupoly_matrix_concat_columns": (C.c_int, [_vp, C.POINTER(C.c_void_p), _sz]),
+    "gpupoly_matrix_split_columns": (C.c_int, [_vp, C.POINTER(C.c_void_p), _sz]),
     "gpupoly_launch_count": (C.c_uint64, []),
     "gpupoly_detmath_eval": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _sz]),
     "gpupoly_device_can_access_peer": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),

@@ -343,6 +343,122 @@ extern "C" int gpupoly_matrix_transpose(GpuMatrix *out, const GpuMatrix *src) {
     ABI_GUARD_END
 }
 
+// ---- column blocks <-> one wide matrix in one launch (extensions) ---------------------------------------------------
+// The host side of a batch of requests (preimage_batched_sharded: several targets against one trapdoor) concatenates
+// the requests' matrices column-wise, makes ONE call, and cuts the result up again.  Through gpu_matrix_copy_block that
+// is a launch per request each way - at the small rings of the GGH15 chain the launches ARE the cost.  Here the blocks'
+// addresses travel as a kernel argument (64 per launch) and one kernel moves every polynomial, 16 bytes per lane.
+#define COLUMN_BLOCKS_MAX 64
+struct ColumnBlocks {
+    uint32_t count;
+    uint32_t start[COLUMN_BLOCKS_MAX + 1];  // first column of block j in the wide matrix; start[count] = one past the last
+    void *ptr[COLUMN_BLOCKS_MAX];
+};
+template <bool SPLIT>
+__global__ void column_blocks_kernel(uint4 *__restrict__ whole, ColumnBlocks blocks, size_t rows, size_t cols, size_t vec_per_poly) {
+    const size_t span = blocks.start[blocks.count] - blocks.start[0];  // columns this launch covers
+    const size_t entry = static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y;
+    if (entry >= rows * span) return;
+    const size_t r = entry / span;
+    const uint32_t c = blocks.start[0] + static_cast<uint32_t>(entry - r * span);
+    uint32_t lo = 0, hi = blocks.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (c >= blocks.start[mid]) lo = mid;
+        else hi = mid;
+    }
+    const size_t bc = blocks.start[lo + 1] - blocks.start[lo];
+    uint4 *w = whole + (r * cols + c) * vec_per_poly;
+    uint4 *b = static_cast<uint4 *>(blocks.ptr[lo]) + (r * bc + (c - blocks.start[lo])) * vec_per_poly;
+    for (size_t v = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; v < vec_per_poly;
+         v += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        if (SPLIT) b[v] = w[v];
+        else w[v] = b[v];
+    }
+}
+
+static int column_blocks(GpuMatrix *whole, GpuMatrix *const *blocks, size_t n, bool split, const char *who) {
+    if (!whole || (n && !blocks)) return set_error(std::string(who) + ": null argument");
+    size_t total = 0;
+    for (size_t j = 0; j < n; ++j) {
+        const GpuMatrix *b = blocks[j];
+        if (!b) return set_error(std::string(who) + ": null block");
+        if (b == whole) return set_error(std::string(who) + ": a block must not alias the wide matrix");
+        if (b->ctx != whole->ctx || b->level != whole->level) return set_error(std::string(who) + ": context / level mismatch");
+        if (b->rows != whole->rows) return set_error(std::string(who) + ": blocks must have the wide matrix's row count");
+        if (split ? false : b->format != blocks[0]->format) return set_error(std::string(who) + ": blocks must share one format");
+        total += b->cols;
+    }
+    if (total != whole->cols) return set_error(std::string(who) + ": the blocks' columns must add up to the wide matrix's");
+    if (split) {
+        for (size_t j = 0; j < n; ++j) blocks[j]->format = whole->format;
+    } else if (n) {
+        whole->format = blocks[0]->format;
+    }
+    if (whole->rows == 0 || total == 0) return 0;
+    GpuContext *ctx = whole->ctx;
+    if (ctx_activate(ctx)) return 1;
+    const size_t poly_bytes = matrix_limbs(whole) * static_cast<size_t>(ctx->N) * ctx->word_bytes;
+    if (poly_bytes % 16 != 0) {  // rings below 16 bytes per limb vector: block by block through the rectangular copy
+        size_t at = 0;
+        for (size_t j = 0; j < n; ++j) {
+            if (blocks[j]->cols) {
+                const int rc = split ? gpu_matrix_copy_block(blocks[j], whole, 0, 0, 0, at, whole->rows, blocks[j]->cols)
+                                     : gpu_matrix_copy_block(whole, blocks[j], 0, at, 0, 0, whole->rows, blocks[j]->cols);
+                if (rc) return rc;
+            }
+            at += blocks[j]->cols;
+        }
+        return 0;
+    }
+    const size_t vec_per_poly = poly_bytes / 16;
+    const unsigned gx = static_cast<unsigned>(std::min<size_t>((vec_per_poly + 255) / 256, 64));
+    size_t at = 0, j = 0;
+    while (j < n) {
+        ColumnBlocks cb;
+        cb.count = 0;
+        const size_t first = at;
+        while (j < n && cb.count < COLUMN_BLOCKS_MAX) {
+            if (blocks[j]->cols) {
+                cb.start[cb.count] = static_cast<uint32_t>(at);
+                cb.ptr[cb.count] = blocks[j]->data;
+                ++cb.count;
+                at += blocks[j]->cols;
+            }
+            ++j;
+        }
+        for (uint32_t t = cb.count; t <= COLUMN_BLOCKS_MAX; ++t) cb.start[t] = static_cast<uint32_t>(at);
+        for (uint32_t t = cb.count; t < COLUMN_BLOCKS_MAX; ++t) cb.ptr[t] = nullptr;
+        if (cb.count == 0) break;
+        const size_t entries = whole->rows * (at - first);
+        const size_t gy = std::min<size_t>(entries, 65535), gz = (entries + gy - 1) / gy;
+        if (gz > 65535 || at >> 32) return set_error(std::string(who) + ": matrix too large");
+        MXX_TRACE_BYTES(2.0 * static_cast<double>(entries) * poly_bytes);
+        if (split)
+            MXX_LAUNCH(column_blocks_kernel<true>, dim3(gx, static_cast<unsigned>(gy), static_cast<unsigned>(gz)), dim3(256), 0, ctx->stream,
+                       static_cast<uint4 *>(whole->data), cb, whole->rows, whole->cols, vec_per_poly);
+        else
+            MXX_LAUNCH(column_blocks_kernel<false>, dim3(gx, static_cast<unsigned>(gy), static_cast<unsigned>(gz)), dim3(256), 0, ctx->stream,
+                       static_cast<uint4 *>(whole->data), cb, whole->rows, whole->cols, vec_per_poly);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// out = [blocks[0] | blocks[1] | ...]: `out` is rows x (sum of the blocks' columns) and takes the blocks' format tag
+extern "C" int gpupoly_matrix_concat_columns(GpuMatrix *out, const GpuMatrix *const *blocks, size_t n) {
+    ABI_GUARD_BEGIN
+    return column_blocks(out, const_cast<GpuMatrix *const *>(blocks), n, false, "gpupoly_matrix_concat_columns");
+    ABI_GUARD_END
+}
+
+// blocks[j] = the next blocks[j]->cols columns of `src`; the blocks take src's format tag
+extern "C" int gpupoly_matrix_split_columns(const GpuMatrix *src, GpuMatrix *const *blocks, size_t n) {
+    ABI_GUARD_BEGIN
+    return column_blocks(const_cast<GpuMatrix *>(src), blocks, n, true, "gpupoly_matrix_split_columns");
+    ABI_GUARD_END
+}
+
 // ---- constant matrices written on the device (extensions) ----------------------------------------
 // The reference's wrapper builds zero and identity matrices as host byte vectors of the full size (8 bytes per
 // residue) and uploads them (src/matrix/gpu_dcrt_poly.rs:343-365 `new_zero_with_state`, :1158-1188 `identity`):

@@ -42,6 +42,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <cstdlib>
 
 #include "detmath.h"
@@ -697,6 +698,56 @@ constexpr uint32_t kSamplerPerLaneCap = SAMPLER_PER_LANE_CAP;
 #ifndef SAMPLER_THREADS
 #define SAMPLER_THREADS 64
 #endif
+// ---- column segments: several independent requests sampled by ONE launch -------------------------------------------
+// The GGH15 callers hand `preimage_batched_sharded` dozens of small requests against one trapdoor
+// (src/sampler/trapdoor/gpu.rs:371-397, src/lookup/ggh15/pubkey_gpu.rs:615-971); at n = 256 a request of four columns
+// leaves the chip ~97 % idle and lasts as long as its unluckiest lane's chain of dependent Karney steps.  The *_segments
+// entry points sample the column-wise concatenation of such requests in one launch: segment j = columns
+// [start[j], start[j + 1]) carries its own seed, and every element's stream is keyed by its position INSIDE its segment
+// (local column, the segment's own column count), so the columns of segment j equal - bit for bit - what the plain entry
+// point writes for a matrix of that segment's shape under that seed.  The table travels as a kernel argument (kernarg
+// memory: wave-uniform scalar loads); the lane kernels take it in their UNI form only - a wave's chunk inside one
+// polynomial / column - so the key stays in scalar registers exactly as in the single-seed kernels.
+#define RNG_MAX_SEGMENTS 64
+struct RngSegments {
+    uint32_t count;
+    uint32_t start[RNG_MAX_SEGMENTS + 1];  // first column of segment j; start[count] = all columns
+    ChaChaKey key[RNG_MAX_SEGMENTS];       // chacha_subkey(seed_j, 0, the sampler's domain tag)
+};
+struct NoSegments {};
+template <bool SEG>
+using SegArg = typename std::conditional<SEG, RngSegments, NoSegments>::type;
+
+#if defined(__HIPCC__)
+// segment of column `col` (binary search; with a wave-uniform `col` everything here runs on the scalar unit)
+__device__ __forceinline__ uint32_t rng_segment_of(const RngSegments &s, uint32_t col) {
+    uint32_t lo = 0, hi = s.count;  // start[lo] <= col < start[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (col >= s.start[mid]) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+#endif
+
+// host side: the table of `nseg` segments (seeds, column counts) under a sampler's domain tag; false if it does not fit
+static inline bool rng_segments_build(RngSegments &out, const GpuRngSeed *seeds, const size_t *seg_cols, size_t nseg,
+                                      uint64_t domain_tag, size_t total_cols) {
+    if (nseg == 0 || nseg > RNG_MAX_SEGMENTS || !seeds || !seg_cols) return false;
+    size_t at = 0;
+    out.count = static_cast<uint32_t>(nseg);
+    for (size_t j = 0; j < nseg; ++j) {
+        if (seg_cols[j] == 0 || at + seg_cols[j] > 0xffffffffull) return false;
+        out.start[j] = static_cast<uint32_t>(at);
+        out.key[j] = chacha_subkey(seeds[j], 0, domain_tag);
+        at += seg_cols[j];
+    }
+    for (size_t j = nseg; j <= RNG_MAX_SEGMENTS; ++j) out.start[j] = static_cast<uint32_t>(at);
+    for (size_t j = nseg; j < RNG_MAX_SEGMENTS; ++j) out.key[j] = ChaChaKey{};
+    return at == total_cols;
+}
+
 static inline uint32_t sampler_per_lane(size_t total, const void *kernel, int device, int forced) {
     if (forced >= 1) return static_cast<uint32_t>(forced);
     int blocks_per_cu = 0, cus = 0;

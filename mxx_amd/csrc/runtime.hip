@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <iterator>
+#include <map>
 #include <cstring>
 #include <dlfcn.h>
 
@@ -50,19 +51,28 @@ struct TraceEntry {
 };
 std::mutex g_trace_mutex;
 std::vector<TraceEntry> g_trace;
-std::vector<hipEvent_t> g_trace_pool;  // events of earlier traces, reused
+// events of earlier traces, reused - one pool per device: an event belongs to the device that was current when it was
+// created, and recording it on another device's stream fails with an invalid handle
+std::map<int, std::vector<hipEvent_t>> g_trace_pool;
 std::string g_trace_report;
 thread_local double t_trace_bytes = 0;
 thread_local long t_trace_open = -1;
-hipEvent_t trace_event() {
-    if (!g_trace_pool.empty()) {
-        hipEvent_t e = g_trace_pool.back();
-        g_trace_pool.pop_back();
+hipEvent_t trace_event(int device) {
+    std::vector<hipEvent_t> &pool = g_trace_pool[device];
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
         return e;
     }
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+        (void)hipGetLastError();  // the caller's own hipGetLastError() after its launch must not see this one
+        return nullptr;
+    }
     return e;
+}
+void trace_event_return(int device, hipEvent_t e) {
+    if (e) g_trace_pool[device].push_back(e);
 }
 }  // namespace
 
@@ -70,13 +80,20 @@ void trace_set_bytes(double bytes) { t_trace_bytes = bytes; }
 
 void trace_launch_begin(const char *name, hipStream_t stream, dim3 grid, dim3 block) {
     std::lock_guard<std::mutex> lk(g_trace_mutex);
-    TraceEntry en{name, trace_event(), trace_event(), 1ull * grid.x * grid.y * grid.z, block.x * block.y * block.z,
-                  t_trace_bytes, 0, false};
+    int device = 0;
+    (void)hipGetDevice(&device);  // the launcher activated the stream's device before calling
+    TraceEntry en{name, trace_event(device), trace_event(device), 1ull * grid.x * grid.y * grid.z, block.x * block.y * block.z,
+                  t_trace_bytes, device, false};
     t_trace_bytes = 0;
     t_trace_open = -1;
-    if (!en.e0 || !en.e1) return;
-    (void)hipGetDevice(&en.device);
-    if (hipEventRecord(en.e0, stream) != hipSuccess) return;
+    if (!en.e0 || !en.e1 || hipEventRecord(en.e0, stream) != hipSuccess) {
+        // a launch that cannot be traced is still launched: hand the events back and leave no HIP error behind for the
+        // launcher's HIP_TRY(hipGetLastError()) to trip over
+        (void)hipGetLastError();
+        trace_event_return(device, en.e0);
+        trace_event_return(device, en.e1);
+        return;
+    }
     g_trace.push_back(en);
     t_trace_open = static_cast<long>(g_trace.size()) - 1;
 }
@@ -86,6 +103,7 @@ void trace_launch_end(hipStream_t stream) {
     if (t_trace_open < 0 || static_cast<size_t>(t_trace_open) >= g_trace.size()) return;
     TraceEntry &en = g_trace[static_cast<size_t>(t_trace_open)];
     en.closed = hipEventRecord(en.e1, stream) == hipSuccess;
+    if (!en.closed) (void)hipGetLastError();
     t_trace_open = -1;
 }
 
@@ -110,8 +128,8 @@ extern "C" int gpupoly_trace_begin(void) {
     ABI_GUARD_BEGIN
     std::lock_guard<std::mutex> lk(g_trace_mutex);
     for (const TraceEntry &en : g_trace) {
-        g_trace_pool.push_back(en.e0);
-        g_trace_pool.push_back(en.e1);
+        trace_event_return(en.device, en.e0);
+        trace_event_return(en.device, en.e1);
     }
     g_trace.clear();
     g_trace_on.store(1, std::memory_order_relaxed);
@@ -145,8 +163,8 @@ extern "C" const char *gpupoly_trace_end(void) {
             g_trace_report += line;
         }
         for (const TraceEntry &en : g_trace) {  // the events go back to the pool: a second _end reports nothing
-            g_trace_pool.push_back(en.e0);
-            g_trace_pool.push_back(en.e1);
+            trace_event_return(en.device, en.e0);
+            trace_event_return(en.device, en.e1);
         }
         g_trace.clear();
         (void)hipSetDevice(prev);

@@ -158,11 +158,15 @@ __global__ void __launch_bounds__(256) sample_small_kernel(W *__restrict__ out, 
 // UNI: every wave's chunk of groups lies inside one polynomial (the launcher checks that 64 * per_lane divides the groups
 // per polynomial): its (row, column) - a 32-bit division - is then computed once per wave on the scalar unit instead of in
 // every group hand-over
-template <int SV, bool UNI = false>
+// SEG (with UNI): the matrix is the column-wise concatenation of independently seeded segments (rng.h, RngSegments); the
+// wave's polynomial lies in one segment, whose sub-key and shape replace `key`, `full_ncol` and `col_offset` - all
+// wave-uniform, read from the kernel argument on the scalar unit.
+template <int SV, bool UNI = false, bool SEG = false>
 __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *__restrict__ stage, size_t polys,
                                     uint32_t local_ncol, size_t full_ncol, size_t col_offset, uint32_t logN,
                                     double sigma, KarneyDivisor div, ChaChaKey key, uint32_t per_lane, uint32_t fill_every,
-                                    int starve_limit) {
+                                    int starve_limit, SegArg<SEG> segs = SegArg<SEG>{}) {
+    static_assert(!SEG || UNI, "segments need a wave's chunk inside one polynomial");
     __shared__ uint32_t ring[SAMPLER_THREADS * RNG_RING_SLOTS];  // 128 bytes per lane: 8 KB per one-wave workgroup
     const uint32_t glog = logN < GAUSS_GROUP_LOG ? logN : GAUSS_GROUP_LOG;
     const uint32_t G = 1u << glog;
@@ -170,7 +174,12 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) sample_gauss_kernel(int64_t *
     WaveChunk chunk = wave_chunk(total, per_lane);
     const uint32_t p_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(chunk.base >> (logN - glog))));
     const uint32_t row_u = p_u / local_ncol, lcol_u = p_u - row_u * local_ncol;
-    const uint64_t stream0_u = row_u * full_ncol + col_offset + lcol_u + 1;
+    uint64_t stream0_u = row_u * full_ncol + col_offset + lcol_u + 1;
+    if constexpr (SEG) {
+        const uint32_t j = rng_segment_of(segs, lcol_u);
+        key = segs.key[j];
+        stream0_u = static_cast<uint64_t>(row_u) * (segs.start[j + 1] - segs.start[j]) + (lcol_u - segs.start[j]) + 1;
+    }
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
     KarneyFsm f;
@@ -421,7 +430,7 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
     MXX_LAUNCH((sample_gauss_kernel<SV, UNI>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream, static_cast<int64_t *>(stage), polys, \
                static_cast<uint32_t>(out->cols), full_ncol, col_offset, ctx->logN, sigma, div, key, per_lane,                   \
                static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : (per_lane == 1 ? 1 : 3)),      \
-               per_lane == 1 ? 1 : 65)
+               per_lane == 1 ? 1 : 65, NoSegments{})
         if (per_lane == 1) {
             if (uni) LAUNCH_SG(1, true);
             else LAUNCH_SG(1, false);
@@ -466,10 +475,64 @@ int sample_impl(GpuMatrix *out, int dist, double sigma, GpuRngSeed seed, size_t 
     return launch_ntt(ctx, out->data, polys * L, static_cast<int>(L), false);
 }
 
+// ---- several independently seeded requests in one launch (rng.h, RngSegments) ---------------------------------------
+// out = [S_0 | S_1 | ...], S_j = what gpu_matrix_sample_distribution writes for a rows x seg_cols[j] matrix under seeds[j].
+// Gaussian only (the perturbation p2 of batched preimage requests); finishes in EVAL like the plain entry point.
+extern "C" int gpupoly_matrix_sample_distribution_segments(GpuMatrix *out, int dist_type, double sigma, const GpuRngSeed *seeds,
+                                                           const size_t *seg_cols, size_t nseg) {
+    ABI_GUARD_BEGIN
+    if (!out) return set_error("gpupoly_matrix_sample_distribution_segments: null matrix");
+    if (dist_type != GPU_MATRIX_DIST_GAUSS)
+        return set_error("gpupoly_matrix_sample_distribution_segments: unsupported: only the Gaussian distribution is segmented");
+    if (!(sigma > 0.0)) return set_error("gpupoly_matrix_sample_distribution_segments: sigma must be positive for Gaussian sampling");
+    GpuContext *ctx = out->ctx;
+    if (ctx->env.rng_compat)
+        return set_error("gpupoly_matrix_sample_distribution_segments: unsupported under MXX_HIP_RNG_COMPAT=reference");
+    RngSegments segs;
+    if (!rng_segments_build(segs, seeds, seg_cols, nseg, kTagGauss, out->cols))
+        return set_error("gpupoly_matrix_sample_distribution_segments: segments must be 1..64, non-empty and cover the matrix's columns");
+    const size_t polys = matrix_polys(out);
+    const uint32_t glog = ctx->logN < GAUSS_GROUP_LOG ? ctx->logN : GAUSS_GROUP_LOG;
+    const size_t groups_per_poly = static_cast<size_t>(ctx->N) >> glog;
+    if (groups_per_poly % SAMPLER_THREADS)
+        return set_error("gpupoly_matrix_sample_distribution_segments: unsupported: ring too small for a wave per polynomial chunk");
+    if (polys >> 32) return set_error("gpupoly_matrix_sample_distribution_segments: too many polynomials");
+    out->format = GPU_POLY_FORMAT_EVAL;
+    if (polys == 0) return 0;
+    if (ctx_activate(ctx)) return 1;
+    const size_t total = polys * static_cast<size_t>(ctx->N);
+    const size_t groups = total >> glog;
+    const uint32_t L = static_cast<uint32_t>(matrix_limbs(out));
+    // the plain launcher's lane count, cut down to a divisor of a polynomial's groups: a wave's chunk stays inside one
+    // polynomial, i.e. inside one segment
+    uint32_t per_lane = sampler_per_lane(groups, reinterpret_cast<const void *>(sample_gauss_kernel<KARNEY_SERVICES, true, true>), ctx->device, ctx->env.sampler_per_lane);
+    while ((groups_per_poly / SAMPLER_THREADS) % per_lane) --per_lane;
+    const unsigned blocks = static_cast<unsigned>((groups + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
+    const KarneyDivisor div = karney_divisor(sigma);
+    void *stage = nullptr;
+    if (ctx_alloc(ctx, total * sizeof(int64_t), &stage)) return 1;
+    MXX_TRACE_BYTES(static_cast<double>(total) * sizeof(int64_t));
+#define LAUNCH_SGS(SV)                                                                                                         \
+    MXX_LAUNCH((sample_gauss_kernel<SV, true, true>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream, static_cast<int64_t *>(stage), polys, \
+               static_cast<uint32_t>(out->cols), out->cols, size_t(0), ctx->logN, sigma, div, ChaChaKey{}, per_lane,            \
+               static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : (per_lane == 1 ? 1 : 3)),      \
+               per_lane == 1 ? 1 : 65, segs)
+    if (per_lane == 1) LAUNCH_SGS(1);
+    else LAUNCH_SGS(KARNEY_SERVICES);
+#undef LAUNCH_SGS
+    const hipError_t err = hipGetLastError();
+    const int rc = err == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
+    ctx_free(ctx, stage);
+    HIP_TRY(err);
+    if (rc) return rc;
+    return launch_ntt(ctx, out->data, polys * L, static_cast<int>(L), false);
+    ABI_GUARD_END
+}
+
 // ---- detmath.h where it runs (extension, test instrument) ------------------------------------------------------
 // Box-Muller's log / cos(2 pi u) are fixed IEEE operation sequences compiled into the device code; this entry evaluates
 // them ON THE DEVICE for caller-supplied arguments so that a test can compare them with libm / extended precision
-// (tests/test_gpu_sampler_stats.py: 10^7 points, <= 2 ulp) - the CPU-side check alone compares the header with itself.
+// (tests/test_gpu_sampler_stats.py: 10^7 points, <= 2 ulp; cos(2 pi x) <= 3 ulp) - the CPU-side check alone compares the header with itself.
 __global__ void detmath_eval_kernel(double *__restrict__ out, const double *__restrict__ in, size_t n, int fn) {
     const size_t i = item_index();
     if (i >= n) return;

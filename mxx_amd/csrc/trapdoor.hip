@@ -198,17 +198,29 @@ static inline GqPertConsts gq_pert_consts(uint32_t dpt, uint32_t base_bits) {
     return k;
 }
 
-template <typename W, int MAXD>
+// SEG: the source is the column-wise concatenation of independently seeded requests (rng.h, RngSegments; the launcher
+// checks that n is a multiple of 64, so a wave's elements share one polynomial): the segment's sub-key replaces `key`
+// and the stream is keyed by the polynomial's index INSIDE its segment, row * segment columns + local column.
+template <typename W, int MAXD, bool SEG = false>
 __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict__ a_out, uint64_t *__restrict__ left_out,
                                        const W *__restrict__ src, const LimbConst *__restrict__ limbs,
                                        ChaChaKey key, size_t total, uint32_t L, uint32_t logN,
-                                       uint32_t dpt, uint32_t base_bits, double c, GqPertConsts pc) {
+                                       uint32_t dpt, uint32_t base_bits, double c, GqPertConsts pc,
+                                       uint32_t src_cols, SegArg<SEG> segs) {
     static_assert(MAXD <= 4, "GqPertConsts holds four digits");
     const size_t idx = item_index();
     if (idx >= total) return;
     const uint32_t i = static_cast<uint32_t>(idx & ((1u << logN) - 1));
     const uint32_t pt = static_cast<uint32_t>(idx >> logN);
-    const uint32_t p = pt / L, t = pt - p * L;
+    uint32_t p = pt / L;
+    const uint32_t t = pt - p * L;
+    if constexpr (SEG) {
+        const uint32_t p_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(p));
+        const uint32_t row = p_u / src_cols, col = p_u - row * src_cols;
+        const uint32_t j = rng_segment_of(segs, col);
+        key = segs.key[j];
+        p = row * (segs.start[j + 1] - segs.start[j]) + (col - segs.start[j]);
+    }
     const uint64_t qt = limbs[t].q;
     uint64_t value = static_cast<uint64_t>(src[idx]);
     if (value >= qt) value %= qt;
@@ -252,13 +264,17 @@ __global__ void __launch_bounds__(256) gauss_samp_prep_kernel(double *__restrict
 // the tower's constants, the polynomial index and the division that finds them are then per-WAVE scalars, read once
 // with scalar loads, instead of a 32-bit division and eleven vector loads with their waits in every element hand-over
 // (the second stall, c_d of the tower at the first integer's hand-over, goes with them).
-template <typename W, int MAXD, int SV, bool UNI = false>
+// SEG (with UNI): independently seeded column segments, as in gauss_samp_prep_kernel - the chunk's polynomial lies in one
+// segment; its sub-key and the polynomial's index inside the segment are per-wave scalars.
+template <typename W, int MAXD, int SV, bool UNI = false, bool SEG = false>
 __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(int64_t *__restrict__ stage,
                                         const LimbConst *__restrict__ limbs, ChaChaKey key,
                                         const GqTower *__restrict__ towers, const double *__restrict__ a_in,
                                         const uint64_t *__restrict__ left_in, size_t total, uint32_t src_cols,
                                         uint32_t L, uint32_t logN, uint32_t dpt, uint32_t base_bits, double c,
-                                        KarneyDivisor div_sigma, uint32_t per_lane, uint32_t fill_every) {
+                                        KarneyDivisor div_sigma, uint32_t per_lane, uint32_t fill_every,
+                                        SegArg<SEG> segs) {
+    static_assert(!SEG || UNI, "segments need a wave's chunk inside one polynomial");
     __shared__ uint32_t ring[SAMPLER_THREADS * RNG_RING_SLOTS];  // 128 bytes per lane: 8 KB per one-wave workgroup
     const uint64_t base = 1ull << base_bits;
     const double base_f = static_cast<double>(base);
@@ -268,8 +284,15 @@ __global__ void __launch_bounds__(SAMPLER_THREADS, 4) gauss_samp_lanes_kernel(in
     WaveChunk chunk = wave_chunk(total, per_lane);
     // UNI: (p, t) of the whole chunk and the tower's record, wave-uniform
     const uint32_t pt_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(chunk.base >> logN)));
-    const uint32_t p_u = pt_u / L, t_u = pt_u - p_u * L;
+    uint32_t p_u = pt_u / L;
+    const uint32_t t_u = pt_u - p_u * L;
     const GqTower tw_u = towers[UNI ? t_u : 0];
+    if constexpr (SEG) {
+        const uint32_t row = p_u / src_cols, col = p_u - row * src_cols;
+        const uint32_t j = rng_segment_of(segs, col);
+        key = segs.key[j];
+        p_u = row * (segs.start[j + 1] - segs.start[j]) + (col - segs.start[j]);
+    }
 
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
@@ -426,9 +449,12 @@ __global__ void __launch_bounds__(256) gauss_samp_expand_kernel(W *__restrict__ 
     }
 }
 
+// segs != nullptr: the source's columns are independently seeded segments (gpupoly_matrix_gauss_samp_gq_arb_base_segments);
+// `seed` is then unused and the lane kernel runs in its UNI form with a lane count that keeps it there
 template <typename W, int MAXD>
 static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t total, uint32_t src_cols, uint32_t L,
-                                   uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
+                                   uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed,
+                                   const RngSegments *segs = nullptr) {
     if ((total >> ctx->logN) >> 32 || k >> 32) return set_error("gpu_matrix_gauss_samp_gq_arb_base: matrix too large");
     // [L] towers | [8][total] words between passes 1 and 2 | [total][dpt] digits
     void *towers = nullptr, *a_buf = nullptr, *stage = nullptr;
@@ -445,11 +471,18 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
                        L, dpt, base_bits, c);
     // per element: the residue read; dpt centres + the 8 - 2 dpt unused keystream words handed to pass 2
     MXX_TRACE_BYTES(static_cast<double>(total) * (sizeof(W) + 8.0 * (8 - dpt)));
-    MXX_LAUNCH((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
-                       ctx->stream, a_words, left_words, src, ctx->d_limbs, key, total, L,
-                       ctx->logN, dpt, base_bits, c, gq_pert_consts(dpt, base_bits));
-    const uint32_t per_lane =
+    if (segs)
+        MXX_LAUNCH((gauss_samp_prep_kernel<W, MAXD, true>), item_grid(total, 256), dim3(256), 0,
+                           ctx->stream, a_words, left_words, src, ctx->d_limbs, key, total, L,
+                           ctx->logN, dpt, base_bits, c, gq_pert_consts(dpt, base_bits), src_cols, *segs);
+    else
+        MXX_LAUNCH((gauss_samp_prep_kernel<W, MAXD>), item_grid(total, 256), dim3(256), 0,
+                           ctx->stream, a_words, left_words, src, ctx->d_limbs, key, total, L,
+                           ctx->logN, dpt, base_bits, c, gq_pert_consts(dpt, base_bits), src_cols, NoSegments{});
+    uint32_t per_lane =
         sampler_per_lane(total, reinterpret_cast<const void *>(gauss_samp_lanes_kernel<W, MAXD, KARNEY_SERVICES>), ctx->device, ctx->env.sampler_per_lane);
+    if (segs)  // a divisor of n / 64: every wave's chunk inside one (polynomial, tower) vector, i.e. inside one segment
+        while ((static_cast<size_t>(ctx->N) / SAMPLER_THREADS) % per_lane) --per_lane;
     const unsigned blocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane));
     const double sigma = c / (static_cast<double>(1ull << base_bits) + 1.0);
     MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * (8 - dpt) + 8.0 * dpt));  // pass 1's words read, dpt int64 digits written
@@ -459,14 +492,23 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
     MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD, SV, UNI>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream,            \
                static_cast<int64_t *>(stage), ctx->d_limbs, key, static_cast<const GqTower *>(towers), a_words, left_words, \
                total, src_cols, L, ctx->logN, dpt, base_bits, c, karney_divisor(sigma), per_lane,                           \
-               static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3))
-    if (per_lane == 1) {
+               static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3), NoSegments{})
+#define LAUNCH_GLS(SV)                                                                                                      \
+    MXX_LAUNCH((gauss_samp_lanes_kernel<W, MAXD, SV, true, true>), dim3(blocks), dim3(SAMPLER_THREADS), 0, ctx->stream,     \
+               static_cast<int64_t *>(stage), ctx->d_limbs, key, static_cast<const GqTower *>(towers), a_words, left_words, \
+               total, src_cols, L, ctx->logN, dpt, base_bits, c, karney_divisor(sigma), per_lane,                           \
+               static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 3), *segs)
+    if (segs) {
+        if (per_lane == 1) LAUNCH_GLS(1);
+        else LAUNCH_GLS(KARNEY_SERVICES);
+    } else if (per_lane == 1) {
         if (uni) LAUNCH_GL(1, true);
         else LAUNCH_GL(1, false);
     } else {
         if (uni) LAUNCH_GL(KARNEY_SERVICES, true);
         else LAUNCH_GL(KARNEY_SERVICES, false);
     }
+#undef LAUNCH_GLS
 #undef LAUNCH_GL
     // the int64 digits and the residue read; every digit written as a residue of every limb (the call's output: 655 MB at M3A)
     MXX_TRACE_BYTES(static_cast<double>(total) * (8.0 * dpt + sizeof(W) + static_cast<double>(dpt) * L * sizeof(W)));
@@ -483,12 +525,14 @@ static int launch_gauss_samp_lanes(GpuContext *ctx, W *out, const W *src, size_t
 
 template <typename W>
 static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys, uint32_t src_cols, uint32_t L,
-                             uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed) {
+                             uint32_t dpt, uint32_t base_bits, double c, size_t k, GpuRngSeed seed,
+                             const RngSegments *segs = nullptr) {
     const size_t total = polys * L * static_cast<size_t>(ctx->N);
     // MXX_HIP_GSAMP=simple keeps the one-thread-per-element kernel for every dpt (A/B runs, tests)
-    const bool simple = ctx->env.gsamp_simple;
-    if (!simple && dpt <= 2) return launch_gauss_samp_lanes<W, 2>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
-    if (!simple && dpt <= 4) return launch_gauss_samp_lanes<W, 4>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed);
+    const bool simple = ctx->env.gsamp_simple && !segs;
+    if (!simple && dpt <= 2) return launch_gauss_samp_lanes<W, 2>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed, segs);
+    if (!simple && dpt <= 4) return launch_gauss_samp_lanes<W, 4>(ctx, out, src, total, src_cols, L, dpt, base_bits, c, k, seed, segs);
+    if (segs) return set_error("gpupoly_matrix_gauss_samp_gq_arb_base_segments: unsupported: more than four digits per tower");
     const dim3 blocks = item_grid(total, 128);
     const uint32_t N = static_cast<uint32_t>(ctx->N);
     MXX_TRACE_BYTES(static_cast<double>(total) * (sizeof(W) + static_cast<double>(dpt) * L * sizeof(W)));
@@ -505,10 +549,35 @@ static int launch_gauss_samp(GpuContext *ctx, W *out, const W *src, size_t polys
     return 0;
 }
 
+static int gauss_samp_impl(GpuMatrix *src, uint32_t base_bits, double c, GpuRngSeed seed, GpuMatrix *out, const RngSegments *segs);
+
 extern "C" int gpu_matrix_gauss_samp_gq_arb_base(GpuMatrix *src, uint32_t base_bits, double c, double dgg_stddev,
                                                  GpuRngSeed seed, GpuMatrix *out) {
     ABI_GUARD_BEGIN
     (void)dgg_stddev;  // unused by the reference too (MatrixTrapdoor.cu:1680)
+    return gauss_samp_impl(src, base_bits, c, seed, out, nullptr);
+    ABI_GUARD_END
+}
+
+// The same over independently seeded column segments (rng.h, RngSegments): columns [sum seg_cols[<j], + seg_cols[j]) of
+// `out` equal what the plain entry point writes for the rows x seg_cols[j] source made of those columns under seeds[j].
+extern "C" int gpupoly_matrix_gauss_samp_gq_arb_base_segments(GpuMatrix *src, uint32_t base_bits, double c, double dgg_stddev,
+                                                              const GpuRngSeed *seeds, const size_t *seg_cols, size_t nseg,
+                                                              GpuMatrix *out) {
+    ABI_GUARD_BEGIN
+    (void)dgg_stddev;
+    if (!src || !out) return set_error("invalid gpupoly_matrix_gauss_samp_gq_arb_base_segments arguments");
+    if (static_cast<size_t>(src->ctx->N) % SAMPLER_THREADS)
+        return set_error("gpupoly_matrix_gauss_samp_gq_arb_base_segments: unsupported: ring too small for a wave per polynomial chunk");
+    RngSegments segs;
+    if (!rng_segments_build(segs, seeds, seg_cols, nseg, kTagGadget, src->cols))
+        return set_error("gpupoly_matrix_gauss_samp_gq_arb_base_segments: segments must be 1..64, non-empty and cover the source's columns");
+    return gauss_samp_impl(src, base_bits, c, GpuRngSeed{}, out, &segs);
+    ABI_GUARD_END
+}
+
+static int gauss_samp_impl(GpuMatrix *src, uint32_t base_bits, double c, GpuRngSeed seed, GpuMatrix *out, const RngSegments *segs) {
+    {
     if (!src || !out) return set_error("invalid gpu_matrix_gauss_samp_gq_arb_base arguments");
     if (base_bits == 0 || base_bits >= 63) return set_error("invalid base_bits in gpu_matrix_gauss_samp_gq_arb_base");
     if (!(c > 0.0)) return set_error("c must be positive in gpu_matrix_gauss_samp_gq_arb_base");
@@ -535,10 +604,10 @@ extern "C" int gpu_matrix_gauss_samp_gq_arb_base(GpuMatrix *src, uint32_t base_b
     }
     int rc = ctx->wide ? launch_gauss_samp<uint64_t>(ctx, static_cast<uint64_t *>(out->data),
                                                      static_cast<const uint64_t *>(src->data), polys,
-                                                     (uint32_t)src->cols, (uint32_t)L, dpt, base_bits, c, k, seed)
+                                                     (uint32_t)src->cols, (uint32_t)L, dpt, base_bits, c, k, seed, segs)
                        : launch_gauss_samp<uint32_t>(ctx, static_cast<uint32_t *>(out->data),
                                                      static_cast<const uint32_t *>(src->data), polys,
-                                                     (uint32_t)src->cols, (uint32_t)L, dpt, base_bits, c, k, seed);
+                                                     (uint32_t)src->cols, (uint32_t)L, dpt, base_bits, c, k, seed, segs);
     if (rc) return rc;
     out->format = GPU_POLY_FORMAT_COEFF;
     if (requested == GPU_POLY_FORMAT_EVAL) {
@@ -547,7 +616,7 @@ extern "C" int gpu_matrix_gauss_samp_gq_arb_base(GpuMatrix *src, uint32_t base_b
         out->format = GPU_POLY_FORMAT_EVAL;
     }
     return 0;
-    ABI_GUARD_END
+    }
 }
 
 // ---- p1 perturbation sampler -------------------------------------------------------------------
@@ -657,14 +726,24 @@ __global__ void p1_divisor_kernel(KarneyDivisor *__restrict__ div, const double 
 // persistent-lane form for m <= 4 (rng.h): element = (column, coefficient), m dependent Karney
 // integers each (rows m-1 .. 0); integers go to the int64 staging array [row][col][N].  Keystream refills every
 // second checkpoint (fill_every; M3A: 0.47 -> 0.445 ms, every third 0.447)
-template <typename W, int MAXM, int SV>
+// SEG: the columns are independently seeded segments (rng.h, RngSegments).  The launcher picks a lane count that keeps
+// every wave's chunk inside one column (64 * per_lane divides n), so the segment's sub-key and the column's index inside
+// its segment - the stream's first word - are per-wave scalars.
+template <typename W, int MAXM, int SV, bool SEG = false>
 __global__ void __launch_bounds__(SAMPLER_THREADS) p1_sample_lanes_kernel(int64_t *__restrict__ stage, const W *__restrict__ tp2,
                                        const double *__restrict__ sqrt_var_base, const double *__restrict__ update_base,
                                        const KarneyDivisor *__restrict__ div_base, uint32_t m, uint32_t cols, uint32_t L,
                                        uint32_t logN, uint64_t q0, double c_scale, ChaChaKey key, size_t total,
-                                       uint32_t per_lane, uint32_t fill_every) {
+                                       uint32_t per_lane, uint32_t fill_every, SegArg<SEG> segs) {
     __shared__ uint32_t ring[SAMPLER_THREADS * RNG_RING_SLOTS];  // 128 bytes per lane: 8 KB per one-wave workgroup
     WaveChunk chunk = wave_chunk(total, per_lane);
+    uint32_t seg_col0 = 0;  // SEG: first column of the chunk's segment
+    if constexpr (SEG) {
+        const uint32_t col_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(chunk.base >> logN)));
+        const uint32_t j = rng_segment_of(segs, col_u < cols ? col_u : cols - 1);
+        key = segs.key[j];
+        seg_col0 = segs.start[j];
+    }
     ChaChaRng rng;
     rng_init_keyed(rng, ring, key, 0, 0, SAMPLER_THREADS);
     KarneyFsm f;
@@ -711,7 +790,7 @@ __global__ void __launch_bounds__(SAMPLER_THREADS) p1_sample_lanes_kernel(int64_
                     if (r < (int)m)
                         mean[r] = c_scale * static_cast<double>(centered_residue(
                                                 tp2[(((static_cast<size_t>(r) * cols + col) * L) << logN) + i], q0));
-                rng_reopen(rng, static_cast<uint64_t>(col) + 1, static_cast<uint64_t>(i) + 1);
+                rng_reopen(rng, static_cast<uint64_t>(col - seg_col0) + 1, static_cast<uint64_t>(i) + 1);
                 t = m - 1;
 #pragma unroll
                 for (int r = 0; r < MAXM; ++r)
@@ -839,9 +918,36 @@ extern "C" void gpu_matrix_destroy_p1_covariance_cache(GpuP1CovarianceCache *cac
     delete cache;
 }
 
+static int sample_p1_impl(const GpuP1CovarianceCache *cache, const GpuMatrix *tp2, GpuRngSeed seed, GpuMatrix *out, const RngSegments *segs);
+
 extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cache, const GpuMatrix *tp2,
                                                 GpuRngSeed seed, GpuMatrix *out) {
     ABI_GUARD_BEGIN
+    return sample_p1_impl(cache, tp2, seed, out, nullptr);
+    ABI_GUARD_END
+}
+
+// The same over independently seeded column segments (rng.h, RngSegments): columns [sum seg_cols[<j], + seg_cols[j]) of
+// `out` equal what the plain entry point writes for those columns of tp2 taken as a matrix of their own under seeds[j].
+extern "C" int gpupoly_matrix_sample_p1_full_cached_segments(const GpuP1CovarianceCache *cache, const GpuMatrix *tp2,
+                                                             const GpuRngSeed *seeds, const size_t *seg_cols, size_t nseg,
+                                                             GpuMatrix *out) {
+    ABI_GUARD_BEGIN
+    if (!cache || !tp2 || !out) return set_error("invalid gpupoly_matrix_sample_p1_full_cached_segments arguments");
+    if (cache->m > 4 || cache->ctx->env.p1_simple)
+        return set_error("gpupoly_matrix_sample_p1_full_cached_segments: unsupported: trapdoor dimension above 2 (no lane kernel)");
+    if (static_cast<size_t>(cache->ctx->N) % SAMPLER_THREADS)
+        return set_error("gpupoly_matrix_sample_p1_full_cached_segments: unsupported: ring too small for a wave per column chunk");
+    RngSegments segs;
+    if (!rng_segments_build(segs, seeds, seg_cols, nseg, kTagP1, tp2->cols))
+        return set_error("gpupoly_matrix_sample_p1_full_cached_segments: segments must be 1..64, non-empty and cover tp2's columns");
+    return sample_p1_impl(cache, tp2, GpuRngSeed{}, out, &segs);
+    ABI_GUARD_END
+}
+
+static int sample_p1_impl(const GpuP1CovarianceCache *cache, const GpuMatrix *tp2, GpuRngSeed seed, GpuMatrix *out,
+                          const RngSegments *segs) {
+    {
     if (!cache || !tp2 || !out) return set_error("invalid gpu_matrix_sample_p1_full_cached arguments");
     GpuContext *ctx = cache->ctx;
     if (tp2->ctx != ctx || out->ctx != ctx) return set_error("context mismatch in gpu_matrix_sample_p1_full_cached");
@@ -871,23 +977,27 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
         // the cache (the cache is per coefficient: re-read per column from L2 / the Infinity Cache), m int64 samples written
         MXX_TRACE_BYTES(static_cast<double>(total) * m * (ctx->word_bytes + 8.0) +
                         static_cast<double>(N) * m * (8.0 + sizeof(KarneyDivisor) + 8.0 * m));
+#define LAUNCH_P1K(WT, MAXM, SV, SEG, SEGARG)                                                                     \
+    MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM, SV, SEG>), dim3(lblocks), dim3(SAMPLER_THREADS), 0, ctx->stream, \
+               static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,                \
+               cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m,           \
+               (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,                       \
+               static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2), SEGARG)
 #define LAUNCH_P1L(WT, MAXM)                                                                                      \
     do {                                                                                                          \
-        const uint32_t per_lane =                                                                                 \
+        uint32_t per_lane =                                                                                       \
             sampler_per_lane(total, reinterpret_cast<const void *>(p1_sample_lanes_kernel<WT, MAXM, KARNEY_SERVICES>), ctx->device, ctx->env.sampler_per_lane); \
+        if (segs) /* a divisor of n / 64: every wave's chunk inside one column, i.e. inside one segment */        \
+            while ((static_cast<size_t>(N) / SAMPLER_THREADS) % per_lane) --per_lane;                             \
         const unsigned lblocks = static_cast<unsigned>((total + SAMPLER_THREADS * per_lane - 1) / (SAMPLER_THREADS * per_lane)); \
-        if (per_lane == 1)                                                                                        \
-            MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM, 1>), dim3(lblocks), dim3(SAMPLER_THREADS), 0, ctx->stream, \
-                       static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,        \
-                       cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m,   \
-                       (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,               \
-                       static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2));     \
-        else                                                                                                      \
-            MXX_LAUNCH((p1_sample_lanes_kernel<WT, MAXM, KARNEY_SERVICES>), dim3(lblocks), dim3(SAMPLER_THREADS), 0, ctx->stream, \
-                       static_cast<int64_t *>(stage), static_cast<const WT *>(tp2->data), cache->sqrt_var,        \
-                       cache->update_coeff, static_cast<const KarneyDivisor *>(cache->karney_div), (uint32_t)m,   \
-                       (uint32_t)cols, L, ctx->logN, ctx->moduli[0], c_scale, key, total, per_lane,               \
-                       static_cast<uint32_t>(ctx->env.sampler_fill_every ? ctx->env.sampler_fill_every : 2));     \
+        if (segs) {                                                                                               \
+            if (per_lane == 1) LAUNCH_P1K(WT, MAXM, 1, true, *segs);                                              \
+            else LAUNCH_P1K(WT, MAXM, KARNEY_SERVICES, true, *segs);                                              \
+        } else if (per_lane == 1) {                                                                               \
+            LAUNCH_P1K(WT, MAXM, 1, false, NoSegments{});                                                         \
+        } else {                                                                                                  \
+            LAUNCH_P1K(WT, MAXM, KARNEY_SERVICES, false, NoSegments{});                                           \
+        }                                                                                                         \
     } while (0)
         if (ctx->wide) {
             if (m <= 2) LAUNCH_P1L(uint64_t, 2);
@@ -897,6 +1007,7 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
             else LAUNCH_P1L(uint32_t, 4);
         }
 #undef LAUNCH_P1L
+#undef LAUNCH_P1K
         const hipError_t le = hipGetLastError();
         int lrc = le == hipSuccess ? launch_scatter_i64(out, static_cast<const int64_t *>(stage)) : 0;
         ctx_free(ctx, stage);
@@ -935,7 +1046,7 @@ extern "C" int gpu_matrix_sample_p1_full_cached(const GpuP1CovarianceCache *cach
     if (rc) return rc;
     out->format = GPU_POLY_FORMAT_EVAL;
     return 0;
-    ABI_GUARD_END
+    }
 }
 
 extern "C" int gpu_matrix_sample_p1_full(const GpuMatrix *a_mat, const GpuMatrix *b_mat, const GpuMatrix *d_mat,

@@ -54,13 +54,15 @@ def _bincode_read_varint(data: bytes, pos: int):
 def block_size() -> int:
     """`BLOCK_SIZE`, default 100 (src/env.rs:175-178): entries per side of a stored matrix block."""
     try:
-        return int(os.environ.get("BLOCK_SIZE", "100"))
+        value = int(os.environ.get("BLOCK_SIZE", "100"))
     except ValueError:
         return 100
+    return value if value >= 1 else 100  # the reference parses a usize: "0" would never advance, a negative value does not parse
 
 
 def block_offsets(rng: range, block: int) -> list:
     """[start, start + block, ..., stop] (gpu_dcrt_poly.rs:1899-1909)."""
+    assert block > 0, "block_offsets: block must be positive"
     offsets, cur = [rng.start], rng.start
     while cur < rng.stop:
         cur = min(cur + block, rng.stop)
@@ -167,7 +169,7 @@ class GpuP1CovarianceCache:
 
 
 class GpuDCRTPolyMatrix:
-    __slots__ = ("params", "nrow", "ncol", "level", "is_ntt", "raw", "_finalizer", "_parent", "__weakref__")
+    __slots__ = ("params", "nrow", "ncol", "level", "is_ntt", "raw", "_finalizer", "_parent", "_version", "__weakref__")
 
     # ------------------------------------------------------------------ construction
     def __init__(self, params: GpuDCRTPolyParams, nrow: int, ncol: int, level: int, is_ntt: bool):
@@ -185,6 +187,7 @@ class GpuDCRTPolyMatrix:
         self.is_ntt = is_ntt
         self.raw = raw
         self._parent = None  # set on row views: the matrix whose storage this one shares
+        self._version = 0  # bumped by every in-place write (and on the parent of a view): keys caches derived from the contents
         self._finalizer = weakref.finalize(self, _ffi.lib().gpu_matrix_destroy, raw)
 
     @classmethod
@@ -259,6 +262,18 @@ class GpuDCRTPolyMatrix:
     def _bytes_per_poly(self) -> int:
         return (self.level + 1) * self.params.ring_dimension() * 8
 
+    def _touch(self) -> None:
+        """contents (or the format tag) are about to change in place: anything cached from them is stale"""
+        m = self
+        while m is not None:
+            m._version += 1
+            m = m._parent
+
+    def content_version(self) -> int:
+        """changes whenever this object's storage was rewritten in place through the host mirror (own writes and writes
+        through row views); caches derived from the contents key on (object, content_version())"""
+        return self._version
+
     def load_rns(self, data: np.ndarray, eval_format: bool) -> None:
         """`load_rns_bytes` (gpu_dcrt_poly.rs:629-663)."""
         data = np.ascontiguousarray(data, dtype=np.uint64)
@@ -269,6 +284,7 @@ class GpuDCRTPolyMatrix:
             raise ValueError("load_rns: size mismatch")
         events = C.c_void_p()
         fmt = GPU_POLY_FORMAT_EVAL if eval_format else GPU_POLY_FORMAT_COEFF
+        self._touch()
         st = _ffi.lib().gpu_matrix_load_rns_batch(self.raw, data.ctypes.data, self._bytes_per_poly(), fmt, C.byref(events))
         check_status(st, "gpu_matrix_load_rns_batch")
         _ffi.wait_and_destroy_events(events)
@@ -298,6 +314,7 @@ class GpuDCRTPolyMatrix:
         buf = np.frombuffer(data, dtype=np.uint8)
         assert len(buf) >= self.nrow * self.ncol * bytes_per_poly, "load_rns_bytes: buffer too small"
         events = C.c_void_p()
+        self._touch()
         st = _ffi.lib().gpu_matrix_load_rns_batch(self.raw, buf.ctypes.data, bytes_per_poly, fmt, C.byref(events))
         check_status(
             st,
@@ -439,6 +456,7 @@ class GpuDCRTPolyMatrix:
         head_room = 64  # the bincode header (6 varints) is written in front of the payload afterwards: one copy in total
         backing = np.empty(head_room + max(cap, 1), dtype=np.uint8)
         max_bits, bpc, plen = C.c_uint16(0), C.c_uint16(0), C.c_size_t(0)
+        self._touch()  # an EVAL matrix is taken to the coefficient domain in place
         st = _ffi.lib().gpu_matrix_store_compact_bytes(
             self.raw, C.c_void_p(backing.ctypes.data + head_room), cap, C.byref(max_bits), C.byref(bpc), C.byref(plen)
         )
@@ -567,12 +585,14 @@ class GpuDCRTPolyMatrix:
         if self.nrow == 0 or self.ncol == 0 or self.is_ntt:
             self.is_ntt = True
             return
+        self._touch()
         check_status(_ffi.lib().gpu_matrix_ntt_all(self.raw), "gpu_matrix_ntt_all")
         self.is_ntt = True
 
     def intt_all_in_place(self) -> None:
         if self.nrow == 0 or self.ncol == 0 or not self.is_ntt:
             return
+        self._touch()
         check_status(_ffi.lib().gpu_matrix_intt_all(self.raw), "gpu_matrix_intt_all")
         self.is_ntt = False
 
@@ -610,6 +630,7 @@ class GpuDCRTPolyMatrix:
         check_status(_ffi.lib().gpupoly_matrix_copy_to_context(params.ctx_raw(), self.raw, C.byref(raw)),
                      "gpupoly_matrix_copy_to_context")
         out.params, out.nrow, out.ncol, out.level, out.is_ntt, out.raw = params, self.nrow, self.ncol, self.level, self.is_ntt, raw
+        out._parent, out._version = None, 0
         out._finalizer = weakref.finalize(out, _ffi.lib().gpu_matrix_destroy, raw)
         return out
 
@@ -625,6 +646,7 @@ class GpuDCRTPolyMatrix:
     def copy_block_from(self, src, dst_row, dst_col, src_row, src_col, rows, cols) -> None:
         if rows == 0 or cols == 0:
             return
+        self._touch()
         st = _ffi.lib().gpu_matrix_copy_block(self.raw, src.raw, dst_row, dst_col, src_row, src_col, rows, cols)
         check_status(st, "gpu_matrix_copy_block")
 
@@ -632,6 +654,7 @@ class GpuDCRTPolyMatrix:
         assert self.params == src.params and self.level == src.level and self.is_ntt == src.is_ntt
         if rows == 0 or cols == 0:
             return
+        self._touch()
         st = _ffi.lib().gpu_matrix_add_block(self.raw, src.raw, dst_row, dst_col, src_row, src_col, rows, cols)
         check_status(st, "gpu_matrix_add_block")
         self.is_ntt = src.is_ntt
@@ -641,6 +664,7 @@ class GpuDCRTPolyMatrix:
         assert lhs.size() == rhs.size() and lhs.ncol == self.ncol and dst_row + lhs.nrow <= self.nrow
         if lhs.is_ntt != rhs.is_ntt:
             rhs = rhs.ensure_eval() if lhs.is_ntt else rhs.ensure_coeff()
+        self._touch()
         check_status(_ffi.lib().gpupoly_matrix_add_rows(self.raw, dst_row, lhs.raw, rhs.raw), "gpupoly_matrix_add_rows")
         self.is_ntt = lhs.is_ntt
 
@@ -653,6 +677,7 @@ class GpuDCRTPolyMatrix:
         v = object.__new__(GpuDCRTPolyMatrix)
         v.params, v.nrow, v.ncol, v.level, v.is_ntt, v.raw = self.params, row_end - row_start, self.ncol, self.level, self.is_ntt, raw
         v._parent = self
+        v._version = 0
         v._finalizer = weakref.finalize(v, _ffi.lib().gpu_matrix_destroy, raw)
         return v
 
@@ -663,6 +688,7 @@ class GpuDCRTPolyMatrix:
         assert coeff.size() == addend.size() and coeff.ncol == self.ncol and dst_row + coeff.nrow <= self.nrow
         assert not coeff.is_ntt, "ntt_add_rows_from takes a coefficient-domain matrix"
         addend = addend.ensure_eval()
+        self._touch()
         st = _ffi.lib().gpupoly_matrix_ntt_add_rows(self.raw, dst_row, coeff.raw, addend.raw, 1 if consume else 0)
         check_status(st, "gpupoly_matrix_ntt_add_rows")
         self.is_ntt = True
@@ -779,6 +805,7 @@ class GpuDCRTPolyMatrix:
         self._check_binop(rhs, "add_in_place")
         if self.nrow == 0 or self.ncol == 0:
             return
+        self._touch()
         check_status(_ffi.lib().gpu_matrix_add(self.raw, self.raw, rhs.raw), "gpu_matrix_add")
         self.is_ntt = rhs.is_ntt
 
@@ -786,6 +813,7 @@ class GpuDCRTPolyMatrix:
         self._check_binop(rhs, "sub_in_place")
         if self.nrow == 0 or self.ncol == 0:
             return
+        self._touch()
         check_status(_ffi.lib().gpu_matrix_sub(self.raw, self.raw, rhs.raw), "gpu_matrix_sub")
         self.is_ntt = rhs.is_ntt
 
@@ -1144,6 +1172,7 @@ class GpuDCRTPolyMatrix:
         out = GpuDCRTPolyMatrix(self.params, self.nrow * self.params.modulus_digits(), self.ncol, self.params.crt_depth() - 1,
                                 not coeff_out)
         self.intt_all_in_place()
+        self._touch()
         st = _ffi.lib().gpu_matrix_gauss_samp_gq_arb_base(self.raw, self.params.base_bits(), c, dgg_stddev, seed, out.raw)
         check_status(st, "gpu_matrix_gauss_samp_gq_arb_base")
         return out
@@ -1163,6 +1192,66 @@ class GpuDCRTPolyMatrix:
         tp2.intt_all_in_place()
         check_status(_ffi.lib().gpu_matrix_sample_p1_full_cached(cache.raw, tp2.raw, seed, out.raw), "gpu_matrix_sample_p1_full_cached")
         return out
+
+    # ---- several independently seeded requests in one launch (gpupoly_*_segments; include/gpupoly.h) ------------------
+    @staticmethod
+    def _segment_args(seeds, seg_cols):
+        assert len(seeds) == len(seg_cols) and seeds, "one seed per segment"
+        return (GpuRngSeed * len(seeds))(*seeds), (C.c_size_t * len(seg_cols))(*seg_cols), len(seeds)
+
+    @classmethod
+    def sample_distribution_segments(cls, params, nrow, seg_cols, dist: int, sigma: float, seeds) -> "GpuDCRTPolyMatrix":
+        """[S_0 | S_1 | ...] with S_j == sample_distribution(params, nrow, seg_cols[j], dist, sigma, seeds[j]), one launch.
+        Raises GpuPolyError (text contains "unsupported") where the library has no segmented form."""
+        out = cls.new_empty(params, nrow, sum(seg_cols))
+        arr, cols, n = cls._segment_args(seeds, seg_cols)
+        check_status(_ffi.lib().gpupoly_matrix_sample_distribution_segments(out.raw, dist, sigma, arr, cols, n),
+                     "gpupoly_matrix_sample_distribution_segments")
+        return out
+
+    @staticmethod
+    def sample_p1_full_cached_segments(cache: GpuP1CovarianceCache, tp2, seeds, seg_cols) -> "GpuDCRTPolyMatrix":
+        """`sample_p1_full_cached` over column segments with a seed each (tp2 is taken to the coefficient domain in place)."""
+        out = GpuDCRTPolyMatrix.new_empty(tp2.params, tp2.nrow, tp2.ncol)
+        arr, cols, n = GpuDCRTPolyMatrix._segment_args(seeds, seg_cols)
+        tp2.intt_all_in_place()
+        check_status(_ffi.lib().gpupoly_matrix_sample_p1_full_cached_segments(cache.raw, tp2.raw, arr, cols, n, out.raw),
+                     "gpupoly_matrix_sample_p1_full_cached_segments")
+        return out
+
+    def gauss_samp_gq_arb_base_segments(self, c: float, dgg_stddev: float, seeds, seg_cols, coeff_out: bool = False) -> "GpuDCRTPolyMatrix":
+        """`gauss_samp_gq_arb_base` over column segments with a seed each; consumes self."""
+        out = GpuDCRTPolyMatrix(self.params, self.nrow * self.params.modulus_digits(), self.ncol, self.params.crt_depth() - 1,
+                                not coeff_out)
+        arr, cols, n = self._segment_args(seeds, seg_cols)
+        self.intt_all_in_place()
+        self._touch()
+        st = _ffi.lib().gpupoly_matrix_gauss_samp_gq_arb_base_segments(self.raw, self.params.base_bits(), c, dgg_stddev, arr, cols, n, out.raw)
+        check_status(st, "gpupoly_matrix_gauss_samp_gq_arb_base_segments")
+        return out
+
+    @staticmethod
+    def _raw_array(ms):
+        return (C.c_void_p * len(ms))(*[m.raw.value if hasattr(m.raw, "value") else m.raw for m in ms])
+
+    @classmethod
+    def concat_columns_of(cls, blocks) -> "GpuDCRTPolyMatrix":
+        """[blocks[0] | blocks[1] | ...] in one launch per 64 blocks (`gpupoly_matrix_concat_columns`); the blocks share one
+        domain (converted copies are made like `concat_columns` does)."""
+        blocks = [blocks[0]] + blocks[0]._same_domain(blocks[1:])
+        first = blocks[0]
+        for b in blocks:
+            assert b.nrow == first.nrow and b.level == first.level and b.params == first.params, "concat_columns_of: block mismatch"
+        out = cls(first.params, first.nrow, sum(b.ncol for b in blocks), first.level, first.is_ntt)
+        check_status(_ffi.lib().gpupoly_matrix_concat_columns(out.raw, cls._raw_array(blocks), len(blocks)), "gpupoly_matrix_concat_columns")
+        return out
+
+    def split_columns(self, widths) -> list:
+        """the column blocks of the given widths, in order, in one launch per 64 blocks (`gpupoly_matrix_split_columns`)"""
+        assert sum(widths) == self.ncol, "split_columns: widths must add up to the column count"
+        outs = [GpuDCRTPolyMatrix(self.params, self.nrow, w, self.level, self.is_ntt) for w in widths]
+        check_status(_ffi.lib().gpupoly_matrix_split_columns(self.raw, self._raw_array(outs), len(outs)), "gpupoly_matrix_split_columns")
+        return outs
 
     def __repr__(self):
         return f"GpuDCRTPolyMatrix({self.nrow}x{self.ncol}, level={self.level}, is_ntt={self.is_ntt})"

@@ -12,7 +12,7 @@ import threading
 import weakref
 
 from .matrix import GpuDCRTPolyMatrix
-from .sampler import DistType, GpuDCRTPolyUniformSampler, random_gpu_rng_seed
+from .sampler import DistType, GpuDCRTPolyUniformSampler, random_gpu_rng_seed, sample_gpu_matrix_with_seed
 
 SPECTRAL_CONSTANT = 1.8  # trapdoor/gpu.rs:15
 
@@ -97,17 +97,25 @@ class GpuDCRTTrapdoor:
     def public_matrix_parts(self, public_matrix: GpuDCRTPolyMatrix):
         """(left, right, [R; E; right]) of A = [left | right] for this trapdoor: the two column blocks the preimage multiplies
         by p1 / p2 and the stacked left factor of the one product over p2 that yields both [R;E] p2 and right p2.  Built once
-        per public-matrix OBJECT (callers keep a trapdoor with its matrix: `src/sampler/trapdoor/gpu.rs:228-369` slices A on
-        every call) and reused while that object is alive; a caller that rewrites the matrix in place must pass a new one."""
+        per public-matrix OBJECT and content version (callers keep a trapdoor with its matrix:
+        `src/sampler/trapdoor/gpu.rs:228-369` slices A on every call) and reused while that object is alive and has not been
+        rewritten in place through the mirror (`GpuDCRTPolyMatrix.content_version`: copy_block_from, add_block_from,
+        load_rns*, the in-place transforms ... all bump it).  The cache pins one copy of A plus the stacked factor in device
+        memory for the trapdoor's lifetime; `clear_public_matrix_cache()` releases it."""
         with self._p1_lock:
-            if self._stacked is not None and self._stacked[0]() is public_matrix:
+            if self._stacked is not None and self._stacked[0]() is public_matrix and self._stacked[2] == public_matrix.content_version():
                 return self._stacked[1]
             d, p1_rows, p2_rows = public_matrix.row_size(), self.re.row_size(), self.re.col_size()
             left = public_matrix.slice(0, d, 0, p1_rows)
             right = public_matrix.slice(0, d, p1_rows, p1_rows + p2_rows)
             parts = (left, right, self.re.concat_rows([right]))
-            self._stacked = (weakref.ref(public_matrix), parts)
+            self._stacked = (weakref.ref(public_matrix), parts, public_matrix.content_version())
             return parts
+
+    def clear_public_matrix_cache(self) -> None:
+        """drop the column blocks / stacked factor kept by `public_matrix_parts` (one A plus [R; E; right] of device memory)"""
+        with self._p1_lock:
+            self._stacked = None
 
     def to_params(self, params) -> "GpuDCRTTrapdoor":
         """Replica of the trapdoor on another device context: two peer copies (R, E) and the small products
@@ -197,16 +205,21 @@ class GpuDCRTPolyTrapdoorSampler:
         p_hat.copy_block_from(p2, p1.row_size(), 0, 0, 0, p2.row_size(), total_ncol)  # both samplers finish in EVAL
         return p_hat
 
-    def _sample_pert_parts(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol, stacked=None):
+    @staticmethod
+    def _draw_seeds():
+        """the three seeds of one preimage call, in the order the reference draws them: p2, p1, z"""
+        return random_gpu_rng_seed(), random_gpu_rng_seed(), random_gpu_rng_seed()
+
+    def _sample_pert_parts(self, params, td: GpuDCRTTrapdoor, s, c, dgg_stddev, sigma_large, total_ncol, stacked=None, seeds=None):
         """The same with the by-products the large-operand assembly reuses.  With `stacked` = [R; E; right] (right = the
         public matrix's columns over p2; `GpuDCRTTrapdoor.public_matrix_parts`) the product right * p2 the caller needs next
         rides in the same pass over p2 as [R;E] p2.  Returns p1, p2, [R;E] p2 (EVAL, kept for the final assembly) and
         right * p2 (or None); the last two are row views of the one product - no copies - and only the p1 sampler, which
         takes its argument to the coefficient domain in place, gets a slice of its own."""
-        u = GpuDCRTPolyUniformSampler()
         d, dk = td.r.row_size(), td.r.col_size()
         padded = -(-total_ncol // d) * d
-        p2 = u.sample_uniform(params, dk, padded, DistType.GaussDist(sigma_large))
+        seed_p2 = seeds[0] if seeds is not None else random_gpu_rng_seed()
+        p2 = sample_gpu_matrix_with_seed(params, dk, padded, DistType.GaussDist(sigma_large), seed_p2)
         rp2 = tp2_eval = None
         if stacked is not None and _traffic_bound(params, dk * padded):
             t = stacked * p2
@@ -219,11 +232,12 @@ class GpuDCRTPolyTrapdoorSampler:
             if _traffic_bound(params, dk * padded):
                 tp2_eval = tp2.clone()
         cache = td.p1_covariance_cache(c, s, dgg_stddev)
-        p1 = GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2, random_gpu_rng_seed())
+        p1 = GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2, seeds[1] if seeds is not None else random_gpu_rng_seed())
         return p1, p2, tp2_eval, rp2
 
-    def preimage(self, params, td: GpuDCRTTrapdoor, public_matrix, target) -> GpuDCRTPolyMatrix:
-        """x with public_matrix * x == target (gpu.rs:228-369)."""
+    def preimage(self, params, td: GpuDCRTTrapdoor, public_matrix, target, _seeds=None) -> GpuDCRTPolyMatrix:
+        """x with public_matrix * x == target (gpu.rs:228-369).  `_seeds` = (p2, p1, z) seeds already drawn by a caller
+        that batches requests (`preimage_many`); otherwise they are drawn here, in that order."""
         d = public_matrix.row_size()
         target_cols = target.col_size()
         assert target.row_size() == d, "Target matrix should have the same number of rows as the public matrix"
@@ -233,7 +247,8 @@ class GpuDCRTPolyTrapdoorSampler:
         p1_rows, p2_rows = td.re.row_size(), td.re.col_size()
         assert public_matrix.col_size() == p1_rows + p2_rows, "public matrix columns must match perturbation rows"
         left, right, stacked = td.public_matrix_parts(public_matrix)
-        p1, p2, tp2, rp2 = self._sample_pert_parts(params, td, s, self.c, self.sigma, dgg_large_std, target_cols, stacked)
+        p1, p2, tp2, rp2 = self._sample_pert_parts(params, td, s, self.c, self.sigma, dgg_large_std, target_cols, stacked, _seeds)
+        seed_z = _seeds[2] if _seeds is not None else None
         assert (p1.row_size(), p2.row_size()) == (p1_rows, p2_rows)
         p_hat_image = (left * p1) + (rp2 if rp2 is not None else right * p2)
         if p_hat_image.col_size() != target_cols:
@@ -246,12 +261,12 @@ class GpuDCRTPolyTrapdoorSampler:
             # the top block follows from it, [R;E] z = [R;E] (p2 + z) - [R;E] p2, with the product read straight
             # from the output's rows and [R;E] p2 kept from the perturbation step - same residues, and z's
             # evaluation form (the largest matrix of the call) is never written or re-read.
-            z = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed(), coeff_out=True)
+            z = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, seed_z if seed_z is not None else random_gpu_rng_seed(), coeff_out=True)
             out.ntt_add_rows_from(p1_rows, z, p2, consume=True)
             re_x = td.re * out.row_view(p1_rows, p1_rows + p2_rows)
             out.add_rows_from(0, p1 - tp2, re_x)
             return out
-        z_hat = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed())
+        z_hat = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, seed_z if seed_z is not None else random_gpu_rng_seed())
         re_z = td.re * z_hat
         if p1.col_size() == target_cols:
             # small operands (launch-bound): the sums written straight into out's row blocks, 3 passes instead of 5
@@ -261,6 +276,50 @@ class GpuDCRTPolyTrapdoorSampler:
         out.copy_block_from(p1, 0, 0, 0, 0, p1_rows, target_cols)
         out.copy_block_from(p2, p1_rows, 0, 0, 0, p2_rows, target_cols)
         out.add_block_from(re_z, 0, 0, 0, 0, re_z.row_size(), target_cols)
+        out.add_block_from(z_hat, 2 * d, 0, 0, 0, z_hat.row_size(), target_cols)
+        return out
+
+    def preimage_reference_sequence(self, params, td: GpuDCRTTrapdoor, public_matrix, target) -> GpuDCRTPolyMatrix:
+        """The SAME preimage through nothing but the reference's own call sequence (gpu.rs:228-369 and
+        `sample_pert_square_mat_gpu_native_parts`, gpu.rs:423-474), i.e. what an unpatched mxx gets from this library: A is
+        sliced and [R; E] concatenated on every call, tp2 is a product of its own, z comes back in EVAL form, R z and E z
+        are two products, and the output is assembled with two copy_block + three add_block calls.  Only entry points the
+        Rust side binds are used (44 `gpu_*` symbols; no `gpupoly_*` extension).  Same distribution and same seeds ->
+        same residues as `preimage` (tests/test_gpu_surface.py); bench.py times it next to the extension sequence."""
+        d = public_matrix.row_size()
+        target_cols = target.col_size()
+        assert target.row_size() == d, "Target matrix should have the same number of rows as the public matrix"
+        n, k = params.ring_dimension(), params.modulus_digits()
+        s = preimage_smoothing_parameter(self.base, self.sigma, d, n, k)
+        dgg_large_std = math.sqrt(s * s - self.c * self.c)
+        # sample_pert_square_mat_gpu_native_parts
+        u = GpuDCRTPolyUniformSampler()
+        dd, dk = td.r.row_size(), td.r.col_size()
+        padded = -(-target_cols // dd) * dd
+        p2 = u.sample_uniform(params, dk, padded, DistType.GaussDist(dgg_large_std))
+        tp2 = td.r.concat_rows([td.e]) * p2
+        cache = td.p1_covariance_cache(self.c, s, self.sigma)
+        p1 = GpuDCRTPolyMatrix.sample_p1_full_cached(cache, tp2, random_gpu_rng_seed())
+        # preimage
+        p1_rows, p2_rows = p1.row_size(), p2.row_size()
+        assert public_matrix.col_size() == p1_rows + p2_rows, "public matrix columns must match perturbation rows"
+        public_left = public_matrix.slice(0, d, 0, p1_rows)
+        public_right = public_matrix.slice(0, d, p1_rows, p1_rows + p2_rows)
+        p_hat_image = (public_left * p1) + (public_right * p2)
+        if p_hat_image.col_size() != target_cols:
+            p_hat_image = p_hat_image.slice_columns(0, target_cols)
+        perturbed = target - p_hat_image
+        z_hat = perturbed.gauss_samp_gq_arb_base(self.c, self.sigma, random_gpu_rng_seed())
+        r_z = td.r * z_hat
+        out = GpuDCRTPolyMatrix(params, p1_rows + p2_rows, target_cols, p1.level, p1.is_ntt)
+        out.copy_block_from(p1, 0, 0, 0, 0, p1_rows, target_cols)
+        out.copy_block_from(p2, p1_rows, 0, 0, 0, p2_rows, target_cols)
+        del p1, p2
+        out.add_block_from(r_z, 0, 0, 0, 0, r_z.row_size(), target_cols)
+        del r_z
+        e_z = td.e * z_hat
+        out.add_block_from(e_z, d, 0, 0, 0, e_z.row_size(), target_cols)
+        del e_z
         out.add_block_from(z_hat, 2 * d, 0, 0, 0, z_hat.row_size(), target_cols)
         return out
 
@@ -275,12 +334,106 @@ class GpuDCRTPolyTrapdoorSampler:
         left = self.preimage(params, td, public_matrix, t)
         return left.concat_rows([right])
 
+    # ---- several requests against one trapdoor in ONE sequence of launches ------------------------------------------
+    BATCH_BYTES = 1 << 30  # cap on the perturbation block p2 of one batch (bounds the batch's device memory)
+
+    @staticmethod
+    def _segments_supported(params, td: GpuDCRTTrapdoor) -> bool:
+        """what the library's *_segments entry points cover (include/gpupoly.h): n a multiple of 128, trapdoor dimension
+        <= 2 (the p1 lane kernel), at most four digits per tower (the G-sampler's lane kernel), default RNG keying"""
+        import os
+
+        dpt = -(-params.crt_bits() // params.base_bits())
+        return (params.ring_dimension() % 128 == 0 and td.r.row_size() <= 2 and dpt <= 4
+                and not os.environ.get("MXX_HIP_RNG_COMPAT", "").startswith("r")
+                and not os.environ.get("MXX_HIP_P1", "").startswith("s")
+                and os.environ.get("MXX_PREIMAGE_BATCH", "1") != "0")
+
+    def preimage_many(self, params, td: GpuDCRTTrapdoor, public_matrix, targets, _seeds=None) -> list:
+        """[preimage(params, td, public_matrix, t) for t in targets] - the SAME matrices, bit for bit, for the same seeds -
+        through one sequence of launches over the column-wise concatenation of the targets.  Every request keeps its own
+        three seeds (drawn here request by request, in the order `preimage` draws them) and the samplers key every element by
+        its position inside its own request (`gpupoly_*_segments`), so batching changes nothing a caller can observe except
+        the time: at n = 256 a four-column request leaves the chip ~97 % idle and lasts as long as its unluckiest lane's
+        chain of Karney steps, and sixteen of them last about as long as one.  Requests whose operands already fill the
+        device (`_traffic_bound`) and shapes the segmented samplers do not cover go through `preimage` one by one."""
+        targets = list(targets)
+        seeds = list(_seeds) if _seeds is not None else [self._draw_seeds() for _ in targets]
+        results = [None] * len(targets)
+        dd, dk = td.r.row_size(), td.r.col_size()
+        word = 4 if max(params.moduli()) < (1 << 31) else 8
+        poly_bytes = params.crt_depth() * params.ring_dimension() * word
+        batchable = []
+        for j, t in enumerate(targets):
+            pad = -(-t.col_size() // dd) * dd
+            if t.col_size() == 0 or _traffic_bound(params, dk * pad) or not self._segments_supported(params, td):
+                results[j] = self.preimage(params, td, public_matrix, t, _seeds=seeds[j])
+            else:
+                batchable.append(j)
+        while batchable:
+            group, size = [], 0
+            while batchable and len(group) < 64:  # RNG_MAX_SEGMENTS per launch
+                j = batchable[0]
+                pad = -(-targets[j].col_size() // dd) * dd
+                if group and size + dk * pad * poly_bytes > self.BATCH_BYTES:
+                    break
+                group.append(batchable.pop(0))
+                size += dk * pad * poly_bytes
+            if len(group) == 1:
+                results[group[0]] = self.preimage(params, td, public_matrix, targets[group[0]], _seeds=seeds[group[0]])
+                continue
+            for j, x in zip(group, self._preimage_segments(params, td, public_matrix, [targets[j] for j in group], [seeds[j] for j in group])):
+                results[j] = x
+        return results
+
+    @staticmethod
+    def _drop_padding(m, cols, pads):
+        """the first cols[j] columns of every pads[j]-wide segment (d > 1 pads a request's perturbation to a multiple of d)"""
+        if cols == pads:
+            return m
+        widths = []
+        for c, p_ in zip(cols, pads):
+            widths += [c, p_ - c]
+        parts = m.split_columns(widths)
+        return GpuDCRTPolyMatrix.concat_columns_of(parts[0::2])
+
+    def _preimage_segments(self, params, td: GpuDCRTTrapdoor, public_matrix, targets, seeds) -> list:
+        """the body of `preimage` (gpu.rs:228-369, :423-474) over [u_0 | u_1 | ...] with a seed triple per segment"""
+        M = GpuDCRTPolyMatrix
+        d = public_matrix.row_size()
+        dd, dk = td.r.row_size(), td.r.col_size()
+        cols = [t.col_size() for t in targets]
+        pads = [-(-c // dd) * dd for c in cols]
+        for t in targets:
+            assert t.row_size() == d, "Target matrix should have the same number of rows as the public matrix"
+        n, k = params.ring_dimension(), params.modulus_digits()
+        s = preimage_smoothing_parameter(self.base, self.sigma, d, n, k)
+        dgg_large_std = math.sqrt(s * s - self.c * self.c)
+        p1_rows, p2_rows = td.re.row_size(), td.re.col_size()
+        assert public_matrix.col_size() == p1_rows + p2_rows, "public matrix columns must match perturbation rows"
+        left, right, _ = td.public_matrix_parts(public_matrix)
+        gauss = DistType.GaussDist(dgg_large_std)
+        p2_pad = M.sample_distribution_segments(params, dk, pads, gauss.as_ffi(), gauss.sigma, [sd[0] for sd in seeds])
+        tp2 = td.re * p2_pad
+        cache = td.p1_covariance_cache(self.c, s, self.sigma)
+        p1_pad = M.sample_p1_full_cached_segments(cache, tp2, [sd[1] for sd in seeds], pads)
+        p1, p2 = self._drop_padding(p1_pad, cols, pads), self._drop_padding(p2_pad, cols, pads)
+        perturbed = M.concat_columns_of(targets) - ((left * p1) + (right * p2))
+        z_hat = perturbed.gauss_samp_gq_arb_base_segments(self.c, self.sigma, [sd[2] for sd in seeds], cols)
+        re_z = td.re * z_hat
+        out = M(params, p1_rows + p2_rows, sum(cols), p1.level, True)
+        out.add_rows_from(0, p1, re_z)
+        out.add_rows_from(p1_rows, p2, z_hat)
+        return out.split_columns(cols)
+
     def preimage_batched_sharded(self, requests):
         """`preimage_batched_sharded` (gpu.rs:371-397): requests = [(entry_idx, params, trapdoor, A, target)];
         every request runs on the device context its params name, and the contexts work concurrently - the
         reference fans out with rayon's `into_par_iter`; here one worker thread per distinct context issues that
-        context's requests in order (the ABI calls release the GIL and never block the host, so the devices'
-        streams fill in parallel).  Results come back in request order, like rayon's collect."""
+        context's requests (the ABI calls release the GIL and never block the host, so the devices' streams fill in
+        parallel), and within a context the requests that share a trapdoor and a public matrix are sampled TOGETHER
+        (`preimage_many`): same outputs as one by one, one sequence of launches.  Results come back in request order,
+        like rayon's collect."""
         from concurrent.futures import ThreadPoolExecutor
 
         groups: dict = {}
@@ -289,8 +442,18 @@ class GpuDCRTPolyTrapdoorSampler:
         results = [None] * len(requests)
 
         def run(items):
+            # requests of one context that share a trapdoor and a public matrix (the GGH15 callers' case: dozens of targets
+            # per key, src/lookup/ggh15/pubkey_gpu.rs:615-971) go through `preimage_many` - one sequence of launches; the
+            # seeds are drawn request by request in the order given, exactly as the one-by-one loop would draw them
+            drawn = {pos: self._draw_seeds() for pos, _ in items}
+            by_key: dict = {}
             for pos, (idx, p, td, a, t) in items:
-                results[pos] = (idx, self.preimage(p, td, a, t))
+                by_key.setdefault((id(td), id(a)), []).append((pos, idx, p, td, a, t))
+            for members in by_key.values():
+                _, _, p, td, a, _ = members[0]
+                outs = self.preimage_many(p, td, a, [m[5] for m in members], _seeds=[drawn[m[0]] for m in members])
+                for (pos, idx, *_), x in zip(members, outs):
+                    results[pos] = (idx, x)
 
         if len(groups) <= 1:
             for items in groups.values():

@@ -182,8 +182,8 @@ void orc_ntt_inverse_plain(uint64_t *x, uint32_t n, uint64_t q, const uint64_t *
             for (uint32_t j = j1; j < j1 + t; ++j) {
                 uint64_t u = x[j];
                 uint64_t v = x[j + t];
-                uint64_t s = u + v; if (s >= q) s -= q;
-                uint64_t d = u >= v ? u - v : u + q - v;
+                uint64_t s = u + v; s -= q & (uint64_t)-(int64_t)(s >= q);
+                uint64_t d = u - v; d += q & (uint64_t)-(int64_t)(u < v);
                 x[j] = s;
                 x[j + t] = orc_mulmod(d, w, q);
             }
@@ -198,7 +198,7 @@ static inline uint64_t shoup(uint64_t w, uint64_t q) { return (uint64_t)(((u128)
 static inline uint64_t mul_shoup(uint64_t x, uint64_t w, uint64_t ws, uint64_t q) {
     uint64_t t = (uint64_t)(((u128)x * ws) >> 64);
     uint64_t r = x * w - t * q;
-    return r >= q ? r - q : r;
+    return r - (q & (uint64_t)-(int64_t)(r >= q));
 }
 
 static void ntt_forward_shoup(uint64_t *x, uint32_t n, uint64_t q, const uint64_t *fwd, const uint64_t *fwds) {
@@ -210,8 +210,10 @@ static void ntt_forward_shoup(uint64_t *x, uint32_t n, uint64_t q, const uint64_
             for (uint32_t j = j1; j < j1 + t; ++j) {
                 uint64_t u = x[j];
                 uint64_t v = mul_shoup(x[j + t], w, ws, q);
-                uint64_t s = u + v; if (s >= q) s -= q;
-                uint64_t d = u >= v ? u - v : u + q - v;
+                /* mask form: both corrections are coin flips on uniform residues, and gcc turned the ?: forms of this loop into
+                 * branches (3x the inverse transform's time, all of it mispredictions) */
+                uint64_t s = u + v; s -= q & (uint64_t)-(int64_t)(s >= q);
+                uint64_t d = u - v; d += q & (uint64_t)-(int64_t)(u < v);
                 x[j] = s;
                 x[j + t] = d;
             }
@@ -229,8 +231,8 @@ static void ntt_inverse_shoup(uint64_t *x, uint32_t n, uint64_t q, const uint64_
             for (uint32_t j = j1; j < j1 + t; ++j) {
                 uint64_t u = x[j];
                 uint64_t v = x[j + t];
-                uint64_t s = u + v; if (s >= q) s -= q;
-                uint64_t d = u >= v ? u - v : u + q - v;
+                uint64_t s = u + v; s -= q & (uint64_t)-(int64_t)(s >= q);
+                uint64_t d = u - v; d += q & (uint64_t)-(int64_t)(u < v);
                 x[j] = s;
                 x[j + t] = mul_shoup(d, w, ws, q);
             }

@@ -22,7 +22,7 @@ b)
     CMD="python3 bench.py --workload $WL --steps $STEPS --warmup 1 --repeats 0 --no-cpu-baseline --no-trace"
     for PASS in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
       TAG=${PASS%%:*}; CTRS=${PASS#*:}
-      rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$TAG -- $CMD > $OUT/pmc_${WL}_$TAG.log 2>&1 || { echo "pmc $WL $TAG failed"; tail -5 $OUT/pmc_${WL}_$TAG.log; exit 1; }
+      rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc_${WL}_$TAG -- $CMD > $OUT/pmc_${WL}_$TAG.log 2>&1 || { echo "pmc $WL $TAG failed"; tail -5 $OUT/pmc_${WL}_$TAG.log; exit 1; }
     done
     python3 tools/pmc_window.py --workload $WL --steps $STEPS --out $OUT/r04_pmc_$WL.json $OUT/pmc_${WL}_fetch $OUT/pmc_${WL}_write $OUT/pmc_${WL}_sq > $OUT/r04_pmc_$WL.txt || exit 1
     rm -rf $OUT/pmc_${WL}_fetch $OUT/pmc_${WL}_write $OUT/pmc_${WL}_sq

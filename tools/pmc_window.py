@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc passes of one bench.py workload -> profiles/r04_pmc_<workload>.json.
+"""rocprofv3 --pmc passes of one bench.py workload -> profiles/pmc_<workload>.json.
+
+The record is VERSIONED: it carries the commit it was collected at (`--head`, handed in by the caller - a GPU box has no
+.git), `gpupoly_version()` and, per kernel, the hash of the kernel's ISA text in the library that ran
+(mxx_amd/codeobj.py).  bench.py uses a kernel's counts only while that hash equals the hash of the kernel in the library it
+is running with, and says `counters_stale` otherwise.
 
 bench.py launches `gpupoly_marker_kernel` on each side of its timed region (ids 1 and 2).  Only the dispatches BETWEEN the
 two markers are counted, so the set-up's launches of the same kernels (other sizes: trapdoor generation, operand sampling,
 warm-up) stay out of the per-launch and per-step figures.  Counters of separate passes (FETCH_SIZE,
 WRITE_SIZE, SQ_*) are joined per kernel; every pass runs the same command, so the window holds the same launches.
 
-    pmc_window.py --workload m3a --steps 3 --out profiles/r04_pmc_m3a.json PASSDIR [PASSDIR ...]
+    pmc_window.py --workload m3a --steps 3 --head <commit> --out profiles/pmc_m3a.json PASSDIR [PASSDIR ...]
 
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE is doubled (gfx950 reports half of the bytes of a wide streaming
 read, MI355X_MICROARCH.md section HBM); WRITE_SIZE is exact for 16-byte-per-lane stores.
@@ -58,6 +63,7 @@ def main():
     ap.add_argument("--steps", type=int, required=True, help="--steps of the profiled bench.py command")
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default=None)
+    ap.add_argument("--head", default=os.environ.get("MXX_HEAD", "unknown"), help="commit of the tree the passes ran on")
     ap.add_argument("passes", nargs="+")
     a = ap.parse_args()
     kern = collections.OrderedDict()
@@ -74,8 +80,17 @@ def main():
                 k["sum"][c] += v
         for base, cnt in seen.items():
             kern[base]["launches"][p] = cnt
-    out = {"workload": a.workload, "steps": a.steps,
-           "source": (a.command or f"rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --workload {a.workload} --steps {a.steps} "
+    from mxx_amd import codeobj
+
+    hashes = codeobj.kernel_isa_hashes()
+    try:
+        from mxx_amd import _ffi
+
+        version = _ffi.lib().gpupoly_version().decode()
+    except Exception as e:  # noqa: BLE001 - the record is still usable without the string
+        version = f"unavailable: {e}"
+    out = {"workload": a.workload, "steps": a.steps, "head": a.head, "gpupoly_version": version, "isa_hash_all": hashes.get("*"),
+           "source": (a.command or f"rocprofv3 --pmc <counters> -- python3 bench.py --workload {a.workload} --steps {a.steps} "
                       "--warmup 1 --repeats 0 --no-cpu-baseline --no-trace") +
                      "; separate passes for FETCH_SIZE, WRITE_SIZE and the SQ counters; only dispatches between bench.py's region "
                      "markers counted (tools/pmc_window.py); FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950",
@@ -84,7 +99,7 @@ def main():
     have_traffic = False
     for base, k in kern.items():
         launches = max(k["launches"].values())
-        rec = {"launches_per_step": launches / a.steps, "full_name": k["full_name"]}
+        rec = {"launches_per_step": launches / a.steps, "full_name": k["full_name"], "isa_hash": hashes.get(base)}
         for c, v in sorted(k["sum"].items()):
             rec[c] = v / a.steps  # per step, summed over the step's launches of this kernel
         if "FETCH_SIZE" in k["sum"] and "WRITE_SIZE" in k["sum"]:
@@ -93,6 +108,9 @@ def main():
             rec["hbm_bytes_per_launch"] = hbm / launches
             total_bytes += hbm / a.steps
             have_traffic = True
+        if k["sum"].get("SQ_THREAD_CYCLES_VALU") and k["sum"].get("SQ_ACTIVE_INST_VALU"):
+            # active lanes per executed VALU instruction (the derived counter VALUUtilization of counter_defs.yaml, as a fraction)
+            rec["lane_utilisation"] = round(k["sum"]["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["sum"]["SQ_ACTIVE_INST_VALU"]), 4)
         out["kernels"][base] = rec
     out["hbm_bytes_per_step"] = total_bytes if have_traffic else None
     json.dump(out, open(a.out, "w"), indent=1)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Static VALU instruction mix of every kernel of libgpupoly -> profiles/r04_valu_mix.json.
+"""Static VALU instruction mix of every kernel of libgpupoly -> profiles/valu_mix.json (versioned: every kernel's record
+carries the hash of its ISA text, mxx_amd/codeobj.py; bench.py ignores a record whose hash is not today's).
 
 bench.py's composed roofline prices a kernel's counted SQ_INSTS_VALU at `cycles_per_inst`: the mix-weighted issue cost
 of its ISA at the measured per-instruction rates (profiles/r02_valu_rates.txt, 4 waves per SIMD: add / sub / and / or / xor
@@ -35,7 +36,7 @@ def kernel_base(name):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_valu_mix.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "valu_mix.json")
     tmp = tempfile.mkdtemp(prefix="valu_mix_")
     agg = collections.defaultdict(lambda: [0, 0])
     try:
@@ -70,14 +71,19 @@ def main():
                 os.remove(os.path.join(tmp, f))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    sys.path.insert(0, ROOT)
+    from mxx_amd import codeobj
+
+    hashes = codeobj.kernel_isa_hashes()
     kernels = {}
     for base, (n, cheap) in sorted(agg.items()):
         if n < 8 or "kernel" not in base:
             continue
-        kernels[base] = {"valu_static": n, "cheap_static": cheap,
+        kernels[base] = {"valu_static": n, "cheap_static": cheap, "isa_hash": hashes.get(base),
                          "cycles_per_inst": round((cheap * CHEAP_CYC + (n - cheap) * OTHER_CYC) / n, 3)}
     json.dump({"prices": {"cheap (add/sub/and/or/xor/mov, f32 add/mul)": CHEAP_CYC, "other": OTHER_CYC,
                           "source": "profiles/r02_valu_rates.txt (tools/valu_rates.hip, 4 waves per SIMD)"},
+               "isa_hash_all": hashes.get("*"),
                "note": "static mix over the kernel's text (all template instances of a kernel pooled); applied to dynamic SQ_INSTS_VALU counts",
                "kernels": kernels}, open(out_path, "w"), indent=1)
     for k, v in kernels.items():
