@@ -737,7 +737,8 @@ class M4Batched(M4):
     """The same chain with the requests a GGH15 caller actually holds at once (src/lookup/ggh15/pubkey_gpu.rs:615-971 hands
     `preimage_batched_sharded` dozens of targets per key): `requests` independent 4-column targets against one trapdoor per
     step, through `preimage_many` (one sequence of launches over the concatenated targets, every request's output identical
-    to what it gets alone), then the requests' encoding products and mul_decompose gates as one `gpupoly_batch` level."""
+    to what it gets alone), then the requests' encoding products as one batched launch and their mul_decompose gates as one
+    call over the concatenated operands (G^-1 works column by column)."""
 
     name = "m4_batched"
     requests = 16
@@ -747,9 +748,10 @@ class M4Batched(M4):
         mx, p = self.mx, self.params
         us = mx.GpuDCRTPolyUniformSampler()
         self.targets = [self.target] + [us.sample_uniform(p, self.dd, 2 * self.dd, mx.DistType.FinRingDist()) for _ in range(self.requests - 1)]
+        self.mmats = [self.mmat] + [us.sample_uniform(p, self.dd, 3, mx.DistType.FinRingDist()) for _ in range(self.requests - 1)]
         self.units = 2 * self.dd * self.requests * self.d.world
         self.desc = (f"M4 batched: {self.requests} requests per step, each = preimage of {2 * self.dd} columns + (1x{self.a0.col_size()})*K "
-                     f"+ mul_decompose; n=256, L={self.depth} (51-bit, u64 words), base 2^17, d={self.dd}; preimage_many + one gpupoly_batch level")
+                     f"+ mul_decompose; n=256, L={self.depth} (51-bit, u64 words), base 2^17, d={self.dd}; preimage_many + mul_batch + one mul_decompose over the concatenated operands")
 
     def step(self, i, mark):
         from mxx_amd import _ffi
@@ -757,10 +759,11 @@ class M4Batched(M4):
         if mark:
             self.mark(i, 0)
         n0 = _ffi.lib().gpupoly_launch_count()
+        M = self.mx.GpuDCRTPolyMatrix
         self.ks = self.sampler.preimage_many(self.params, self.td0, self.a0, self.targets)
-        gates = [("mul", self.c0, k_) for k_ in self.ks] + [("mul_decompose", self.bmat, self.mmat)] * self.requests
-        outs = self.mx.GpuDCRTPolyMatrix.eval_gates(gates)
-        self.c1s, self.mds = outs[: self.requests], outs[self.requests:]
+        self.c1s = M.mul_batch([self.c0] * self.requests, self.ks)  # the requests' encodings times their keys: one launch
+        # B * G^-1(M_j) for every request: the gadget decomposition is column-wise, so the requests' M_j ride in one call
+        self.mds = self.bmat.mul_decompose(M.concat_columns_of(self.mmats)).split_columns([3] * self.requests)
         self.k, self.md = self.ks[0], self.mds[0]
         self.launches_per_step = _ffi.lib().gpupoly_launch_count() - n0
         if mark:
@@ -769,7 +772,7 @@ class M4Batched(M4):
     def check(self):
         for k_, t in zip(self.ks, self.targets):
             assert self.a0 * k_ == t, "A*x != u"
-        assert self.c1s[3] == self.c0 * self.ks[3] and self.mds[5] == self.bmat.mul_decompose(self.mmat)
+        assert self.c1s[3] == self.c0 * self.ks[3] and self.mds[5] == self.bmat.mul_decompose(self.mmats[5])
 
 
 WORKLOADS = {"m1": M1, "m2a": M2A, "m2b": M2B, "m2b_decompose": M2BDecompose, "m2b_mul_decompose": M2BMulDecompose,

@@ -50,9 +50,25 @@ __device__ __forceinline__ void wave_sync() {
 // the plain transform, whose output the next kernel often finds in the Infinity Cache (M1: the fused inverse behind a
 // forward transform with such stores ran 158 -> 185 us).
 // ADD: the vector `addv` (canonical residues, evaluation order) is added to the result on its way out
-template <typename W, bool TIGHT, bool NTS, typename Load, bool ADD = false>
+// GPUPOLY_PHASE_TIMING builds only (tools/build_variant.sh phase PHASE_TIMING=1; tools/ab_ntt_phases.sh; the mask comes from
+// MXX_HIP_NTT_PHASE): `phase` switches parts of the kernel off at run time - bit 0: no global loads (synthetic inputs),
+// bit 1: no butterflies, bit 2: no global stores - to time the memory skeleton and the arithmetic separately.  Results
+// are wrong by design in those modes.
+#ifdef GPUPOLY_PHASE_TIMING
+#define NTT14_PHASE(bit) ((phase & (bit)) != 0)
+#else
+#define NTT14_PHASE(bit) false
+#endif
+// COAL: the finished block takes one more trip through its LDS rows so that every store instruction of a wave covers 1 KB
+// of CONTIGUOUS memory (lane l: 16 bytes at 16 l).  Without it a lane holds 8 consecutive words and its two 16-byte
+// stores sit 32 bytes apart: each instruction half-fills 64 lines, and the two halves of a line reach the memory side as
+// separate partial writes when the store is non-temporal (streams of 1 GiB and more, the digit transforms of a
+// decomposition): "stores only" ran at 1.7 TB/s there (tools/ab_ntt_phases.sh).
+template <typename W, bool TIGHT, bool NTS, typename Load, bool ADD = false, bool COAL = false>
 __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> *__restrict__ tw_all,
-                                         const LimbConst &lc, uint32_t limb, const W *__restrict__ addv = nullptr) {
+                                         const LimbConst &lc, uint32_t limb, const W *__restrict__ addv = nullptr,
+                                         uint32_t phase = 0) {
+    (void)phase;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W *xs = reinterpret_cast<W *>(smem);  // [2][8][BLK_PAD]
     constexpr int VN = 16 / sizeof(W);
@@ -65,8 +81,8 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
     // stages 0..4 in registers: element tid of each of the 32 blocks
     W h[R0];
 #pragma unroll
-    for (int u = 0; u < R0; ++u) h[u] = load(tid + T * u);
-    ct_network_lazy<W, 5>(h, tw, 0, 0, q, twoq);
+    for (int u = 0; u < R0; ++u) h[u] = NTT14_PHASE(1) ? static_cast<W>((tid * 2654435761u + u * 40503u + limb) & 0xffffu) : load(tid + T * u);
+    if (!NTT14_PHASE(2)) ct_network_lazy<W, 5>(h, tw, 0, 0, q, twoq);
 
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
@@ -82,8 +98,10 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             const uint32_t base = pad64(lane);  // pad64(lane + 64 m) = pad64(lane) + 72 m
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[base + 72 * m];
-            ct_prefold<W, 3, TIGHT>(v, q);
-            ct_network_lazy<W, 3>(v, tw, B, 5, q, twoq);
+            if (!NTT14_PHASE(2)) {
+                ct_prefold<W, 3, TIGHT>(v, q);
+                ct_network_lazy<W, 3>(v, tw, B, 5, q, twoq);
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + 72 * m] = v[m];
         }
@@ -93,8 +111,10 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             const uint32_t base = 72 * c + j;  // pad64(64 c + j + 8 m) = 72 c + j + 8 m + 4 (m >> 2)
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m + 4 * (m >> 2)];
-            ct_prefold<W, 3, TIGHT>(v, q);
-            ct_network_lazy<W, 3>(v, tw, B * 8u + c, 8, q, twoq);
+            if (!NTT14_PHASE(2)) {
+                ct_prefold<W, 3, TIGHT>(v, q);
+                ct_network_lazy<W, 3>(v, tw, B * 8u + c, 8, q, twoq);
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) xb[base + 8 * m + 4 * (m >> 2)] = v[m];
         }
@@ -103,10 +123,41 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             const uint32_t base = pad64(8 * lane);
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = xb[base + m];
-            ct_prefold<W, 3, TIGHT>(v, q);
-            ct_network_lazy<W, 3>(v, tw, B * 64u + lane, 11, q, twoq);
+            if (!NTT14_PHASE(2)) {
+                ct_prefold<W, 3, TIGHT>(v, q);
+                ct_network_lazy<W, 3>(v, tw, B * 64u + lane, 11, q, twoq);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = csub<W>(fold_2q<W>(v[m], q, muw), q);
+                for (int m = 0; m < 8; ++m) v[m] = csub<W>(fold_2q<W>(v[m], q, muw), q);
+            }
+            if constexpr (COAL) {
+                typedef W wx __attribute__((ext_vector_type(VN)));
+                // back into the block's own rows (this wave's alone until the barrier two groups on), same slots they came from
+#pragma unroll
+                for (int m = 0; m < 8; m += VN) {
+                    wx t;
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) t[e] = v[m + e];
+                    *reinterpret_cast<wx *>(&xb[base + m]) = t;
+                }
+                wave_sync();
+                constexpr int CH = BLK / (64 * VN);  // store instructions per block: 2 for 32-bit words
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const uint32_t pos = c * 64 * VN + VN * lane;  // VN consecutive words never straddle a padding step (32 words)
+                    wx t = *reinterpret_cast<const wx *>(&xb[pad64(pos)]);
+                    W *dstc = g + B * BLK + pos;
+                    if constexpr (ADD) {
+                        const wx a = __builtin_nontemporal_load(reinterpret_cast<const wx *>(addv + B * BLK + pos));
+#pragma unroll
+                        for (int e = 0; e < VN; ++e) t[e] = csub<W>(t[e] + a[e], q);
+                    }
+                    if (NTT14_PHASE(4)) {
+                        if (t[0] == static_cast<W>(0xdeadbeefu) && t[VN - 1] == static_cast<W>(0x12345u)) dstc[0] = t[0];
+                    } else if constexpr (NTS) __builtin_nontemporal_store(t, reinterpret_cast<wx *>(dstc));
+                    else *reinterpret_cast<wx *>(dstc) = t;
+                }
+                continue;
+            }
             W *dst = g + B * BLK + 8 * lane;
 #pragma unroll
             for (int m = 0; m < 8; m += VN) {
@@ -119,7 +170,9 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
 #pragma unroll
                     for (int e = 0; e < VN; ++e) t[e] = csub<W>(t[e] + a[e], q);
                 }
-                if constexpr (NTS) __builtin_nontemporal_store(t, reinterpret_cast<wx *>(dst + m));
+                if (NTT14_PHASE(4)) {
+                    if (t[0] == static_cast<W>(0xdeadbeefu) && t[VN - 1] == static_cast<W>(0x12345u)) dst[m] = t[0];  // keeps the values alive
+                } else if constexpr (NTS) __builtin_nontemporal_store(t, reinterpret_cast<wx *>(dst + m));
                 else *reinterpret_cast<wx *>(dst + m) = t;
             }
         }
@@ -139,13 +192,27 @@ struct LoadVector {
 template <typename W, bool TIGHT = false, bool NT = false>
 __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     fwd_kernel(W *__restrict__ data, const TwPair<W> *__restrict__ tw_all, const LimbConst *__restrict__ limbs,
-               uint32_t L) {
+               uint32_t L, uint32_t phase = 0) {
     // grid = (L, polys): the limb comes from the block index instead of a runtime division of it
     const uint32_t limb = blockIdx.x;
     const size_t vec = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * L + limb;
     const LimbConst lc = limbs[limb];
     W *g = data + vec * N;
-    fwd_body<W, TIGHT, NT>(g, LoadVector<W, NT>{g}, tw_all, lc, limb);
+#ifdef GPUPOLY_PHASE_TIMING
+    // bit 3 of the phase mask selects the coalesced-store form, bit 4 cacheable stores, whatever the launcher chose
+    if (phase & 8) {
+        if (phase & 16) fwd_body<W, TIGHT, false, LoadVector<W, NT>, false, true>(g, LoadVector<W, NT>{g}, tw_all, lc, limb, nullptr, phase);
+        else fwd_body<W, TIGHT, NT, LoadVector<W, NT>, false, true>(g, LoadVector<W, NT>{g}, tw_all, lc, limb, nullptr, phase);
+    } else if (phase & 16) {
+        fwd_body<W, TIGHT, false>(g, LoadVector<W, NT>{g}, tw_all, lc, limb, nullptr, phase);
+    } else {
+        fwd_body<W, TIGHT, NT>(g, LoadVector<W, NT>{g}, tw_all, lc, limb, nullptr, phase);
+    }
+#else
+    (void)phase;
+    // non-temporal streams (1 GiB and more) store through the coalescing LDS trip: see COAL
+    fwd_body<W, TIGHT, NT, LoadVector<W, NT>, false, NT>(g, LoadVector<W, NT>{g}, tw_all, lc, limb);
+#endif
 }
 
 // out = NTT(src) + add, out of place: the preimage's x = [.. ; p2 + z] takes the G-sampler's coefficient digits, the
@@ -158,7 +225,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     const uint32_t limb = blockIdx.x;
     const size_t vec = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * L + limb;
     const LimbConst lc = limbs[limb];
-    fwd_body<W, TIGHT, true, LoadVector<W, true>, true>(out + vec * N, LoadVector<W, true>{src + vec * N}, tw_all, lc, limb, add + vec * N);
+    fwd_body<W, TIGHT, true, LoadVector<W, true>, true, true>(out + vec * N, LoadVector<W, true>{src + vec * N}, tw_all, lc, limb, add + vec * N);
 }
 
 // Gadget decomposition fused into the transform's load (decompose.hip): output vector
@@ -210,7 +277,7 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     }
     load.q = static_cast<W>(lc.q);
     (void)towers;
-    fwd_body<W, TIGHT, NTS>(out + vec * N, load, tw_all, lc, limb);
+    fwd_body<W, TIGHT, NTS, LoadDigit<W, REDUCE>, false, NTS>(out + vec * N, load, tw_all, lc, limb);
 }
 
 // SGN: the signed butterflies of ntt_lds.h (u32 words, q < 2^24, twiddle table ctx->d_tw2s_inv)

@@ -287,6 +287,10 @@ void EnvSwitches::load() {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 4096) sampler_per_lane = v;
     }
+    if (const char *e = std::getenv("MXX_HIP_NTT_PHASE")) {
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 31) ntt_phase = v;
+    }
     if (const char *e = std::getenv("MXX_HIP_SAMPLER_FILL_EVERY")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 8) sampler_fill_every = v;

@@ -73,6 +73,48 @@ __device__ __forceinline__ uint32_t reconstruct_centered(const W *__restrict__ s
             return mag ? 64u - static_cast<uint32_t>(__clzll(mag)) : 0u;
         }
     }
+    // Second fast path: |x| < q_0 q_1 / 2 - a preimage's entries (perturbations of width ~2^27 against 24-bit limbs) overflow
+    // limb 0 alone but not two limbs.  The candidate is the centred two-limb CRT value c2 (one Garner step, one double-width
+    // word); if every further limb holds c2's residue then x = c2, again by uniqueness of the representative in
+    // (-Q/2, Q/2] (|c2| <= q_0 q_1 / 2 < Q / 2 from three limbs on; with two limbs c2 IS the general result).  O(L) instead
+    // of the O(L^2) recurrence below: the width and pack passes over an M3A preimage went from 3.4 + 2.0 ms to the
+    // time of reading the matrix (bench.py, compact_bytes).
+    if (L >= 2) {
+        typedef typename Wide<W>::type D;
+        const uint64_t q0 = sc.q[0], q1 = sc.q[1];
+        const uint64_t r0m = res[0] >= q1 ? res[0] % q1 : res[0];
+        const uint64_t dd = res[1] >= r0m ? res[1] - r0m : res[1] + q1 - r0m;
+        const uint64_t v1 = static_cast<uint64_t>(barrett_reduce(static_cast<D>(dd) * static_cast<D>(garner[garner_stride]), static_cast<W>(q1), limbs[1].mu, limbs[1].kbits));
+        const D q01 = static_cast<D>(q0) * q1;
+        const D val = static_cast<D>(res[0]) + static_cast<D>(v1) * q0;  // in [0, q_0 q_1)
+        const bool neg2 = val > (q01 >> 1);
+        const D mag2 = neg2 ? q01 - val : val;
+        bool ok = true;
+        auto same2 = [&](int k) {
+            const uint64_t qk = sc.q[k];
+            const uint32_t kb = limbs[k].kbits;
+            const bool fits = 2 * kb >= 8 * sizeof(D) || (mag2 >> (2 * kb)) == 0;  // Barrett's range: mag2 < 2^(2 bits(q_k))
+            const uint64_t r = static_cast<uint64_t>(barrett_reduce(mag2, static_cast<W>(qk), limbs[k].mu, kb));
+            return fits && res[k] == ((neg2 && r) ? qk - r : r);
+        };
+        if constexpr (ML <= 16) {
+#pragma unroll
+            for (int k = 2; k < ML; ++k)
+                if (k < L) ok = ok && same2(k);
+        } else {
+            for (int k = 2; k < L; ++k) ok = ok && same2(k);
+        }
+        if (ok) {
+            for (int w = 0; w < WC; ++w) x[w] = 0;
+            x[0] = static_cast<uint64_t>(mag2);
+            uint64_t hi = 0;
+            if constexpr (sizeof(D) > 8) hi = static_cast<uint64_t>(mag2 >> 64);
+            if (WC > 1) x[1] = hi;
+            negative = neg2 && mag2 != 0;
+            if (hi) return 128u - static_cast<uint32_t>(__clzll(hi));
+            return x[0] ? 64u - static_cast<uint32_t>(__clzll(x[0])) : 0u;
+        }
+    }
     uint64_t v[ML];
     // Garner: v_k = (r_k - (v_0 + v_1 q_0 + ...)) / (q_0 .. q_{k-1})  mod q_k, computed incrementally
     auto garner_step = [&](int k, int j, uint64_t t, uint64_t qk, uint64_t mu, uint32_t kb) {
@@ -159,9 +201,11 @@ __global__ void compact_maxbits_kernel(const W *__restrict__ src, size_t polys, 
         bool neg;
         bits = reconstruct_centered<W, ML>(src, idx / N, static_cast<uint32_t>(idx % N), N, sc, garner, garner_stride, limbs, x, neg);
     }
-    // wave-level max, one atomic per wave
+    // wave-level max; the atomic only when this wave would raise the running maximum.  (One unconditional atomic per wave
+    // was 280 000 read-modify-writes of ONE word for an M3A preimage - serialised in L2, 3.2 ms, the whole kernel; after the
+    // first waves the plain read sees the final width and nearly every wave skips it.)
     for (int off = 32; off > 0; off >>= 1) bits = max(bits, __shfl_down(bits, off));
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_bits, bits);
+    if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(max_bits, __ATOMIC_RELAXED)) atomicMax(max_bits, bits);
 }
 
 template <typename W, int ML>
