@@ -1379,6 +1379,49 @@ def gate_batch_block(mx, device, count=16, reps=20):
                          "note": "launch- and latency-bound: 12 MB of operands"}}
 
 
+def mixed_keys_block(mx, device, keys=8, per_key=2, reps=8):
+    """`preimage_batched_sharded` as the GGH15 evaluation calls it (src/lookup/ggh15/pubkey_gpu.rs:615-971): one call with
+    requests against SEVERAL trapdoors of one context - `keys` trapdoors x `per_key` 4-column targets on the M4 ring.  Requests
+    that share a key are sampled together (`preimage_many`); the key groups run on worker contexts of the same device
+    (MXX_PREIMAGE_WORKERS, default 4), against one after another with MXX_PREIMAGE_WORKERS=1."""
+    p = mx.GpuDCRTPolyParams(256, mx.gen_crt_basis(256, 12, 51), 17, gpu_ids=[device])
+    sampler = mx.GpuDCRTPolyTrapdoorSampler(p, 4.578)
+    us = mx.GpuDCRTPolyUniformSampler()
+    pairs = [sampler.trapdoor(p, 2) for _ in range(keys)]
+    reqs = []
+    for j in range(keys * per_key):
+        td, a = pairs[j % keys]
+        reqs.append((j, p, td, a, us.sample_uniform(p, 2, 4, mx.DistType.FinRingDist())))
+
+    def timed(workers):
+        os.environ["MXX_PREIMAGE_WORKERS"] = str(workers)
+        try:
+            out = None
+            for _ in range(3):
+                out = sampler.preimage_batched_sharded(reqs)
+            ts = []
+            for _ in range(reps):
+                mx.gpu_device_sync()
+                t0 = time.perf_counter()
+                out = sampler.preimage_batched_sharded(reqs)
+                mx.gpu_device_sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return statistics.median(ts), out
+        finally:
+            os.environ.pop("MXX_PREIMAGE_WORKERS", None)
+
+    one_ms, _ = timed(1)
+    many_ms, out = timed(4)
+    for (_, x), (_, _, _, a, t) in zip(out, reqs):
+        assert a * x == t, "A*x != u"
+    cols = 4 * len(reqs)
+    return {"metric": "trapdoor_preimages_per_s", "value": cols / (many_ms * 1e-3), "unit": "preimages/s", "ms_per_step": many_ms,
+            "config": {"workload": f"one preimage_batched_sharded call: {keys} trapdoors x {per_key} requests of 4 columns, n=256, L=12 (51-bit), "
+                                   "d=2; key groups on 4 worker contexts of the device"},
+            "requests_in_flight": len(reqs), "loop_ms": one_ms, "speedup_vs_loop": one_ms / many_ms,
+            "roofline": {"bound": "hbm", "frac": None, "note": "launch- and latency-bound; the figure of merit is the speed-up over one stream"}}
+
+
 # ---------------------------------------------------------------------------------------------------
 # the short line (what the driver parses) built from the full record
 # ---------------------------------------------------------------------------------------------------
@@ -1482,7 +1525,7 @@ def short_line(full):
         configs["m2b_mul_decompose"] = _config_record(m2b.get("mul_decompose"))
     for key, name in (("preimage", "m3a_preimage"), ("preimage_reference_sequence", "m3a_reference_sequence"),
                       ("preimage_m3b", "m3b_preimage"), ("chain_m4", "m4_chain"), ("chain_m4_batched", "m4_chain_batched"),
-                      ("compact_bytes", "compact_bytes"), ("gate_batch", "gate_batch")):
+                      ("preimage_mixed_keys", "m4_mixed_keys"), ("compact_bytes", "compact_bytes"), ("gate_batch", "gate_batch")):
         if full.get(key):
             configs[name] = _config_record(full[key])
     s8 = (full.get("preimage") or {}).get("shard_of_8")
@@ -1673,6 +1716,7 @@ def main():
         line["chain_m4_batched"] = m4b
         if d.world == 1:
             line["gate_batch"] = gate_batch_block(mx, device)
+            line["preimage_mixed_keys"] = mixed_keys_block(mx, device)
         line["baseline_configs"] = {
             "configs[0] (plumbing, n=2^12, L=2, 4x4)": "CPU-runnable parity case: tests/test_gpu_surface.py + tests/test_oracle.py, not a bench line",
             "configs[1] (NTT / INTT / mod-mul, n=2^14, L=4, 1024 polys)": "kernels",

@@ -134,6 +134,10 @@ int gpu_matrix_store_rns_batch(const GpuMatrix *mat, uint8_t *bytes_out, size_t 
                                GpuEventSet **out_events);
 int gpu_matrix_store_const_coeff_batch(const GpuMatrix *mat, uint64_t *words_out, size_t words_per_poly,
                                        GpuEventSet **out_events);
+/* compact wire format (coefficient-domain, CRT-reconstructed, centred, bit-packed at the matrix-wide width): the store
+ * takes an EVAL matrix to the coefficient domain in place.  When payload_capacity is too small the call fails with
+ * "payload buffer too small ..." AND reports the width / length it needs through the three out parameters (the
+ * reference reports only the error), so a host need not reserve the worst case of bits(Q) per coefficient.       */
 int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_out, size_t payload_capacity,
                                    uint16_t *out_max_coeff_bits, uint16_t *out_bytes_per_coeff,
                                    size_t *out_payload_len);

@@ -367,7 +367,14 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     const unsigned int bytes_per_coeff = (width + 7) / 8;
     const size_t total_bits = coeffs * static_cast<size_t>(width);
     const size_t payload_len = (total_bits + 7) / 8;
-    if (payload_len > payload_capacity) return set_error("payload buffer too small in gpu_matrix_store_compact_bytes");
+    if (payload_len > payload_capacity) {
+        // the caller learns the width and the length it needs (the reference reports only the error): a host that does not
+        // want to pin the worst case - bits(Q) per coefficient - retries once with the exact size
+        *out_max_coeff_bits = static_cast<uint16_t>(width);
+        *out_bytes_per_coeff = static_cast<uint16_t>(bytes_per_coeff);
+        *out_payload_len = payload_len;
+        return set_error("payload buffer too small in gpu_matrix_store_compact_bytes");
+    }
     if (payload_len > 0) {
         if (!payload_out) return set_error("null payload buffer in gpu_matrix_store_compact_bytes");
         const size_t padded = (payload_len + 3) / 4 * 4 + 4;

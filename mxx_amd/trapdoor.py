@@ -74,6 +74,7 @@ class GpuDCRTTrapdoor:
         self._p1_cache = None
         self._p1_lock = threading.Lock()
         self._stacked = None  # ([R; E; right], the public-matrix block it was built from): see stacked_left_factor
+        self._replicas = {}   # context handle -> (trapdoor, public matrix, ...) in that context: see replica_for
 
     @classmethod
     def new(cls, params, size: int, sigma: float) -> "GpuDCRTTrapdoor":
@@ -113,9 +114,25 @@ class GpuDCRTTrapdoor:
             return parts
 
     def clear_public_matrix_cache(self) -> None:
-        """drop the column blocks / stacked factor kept by `public_matrix_parts` (one A plus [R; E; right] of device memory)"""
+        """drop the column blocks / stacked factor kept by `public_matrix_parts` (one A plus [R; E; right] of device memory)
+        and the replicas kept by `replica_for`"""
         with self._p1_lock:
             self._stacked = None
+            self._replicas = {}
+
+    def replica_for(self, params, public_matrix: GpuDCRTPolyMatrix):
+        """(trapdoor, public matrix) in the context of `params` - another stream on the same device (a worker context of
+        `preimage_batched_sharded`) or another device: device-to-device copies of R, E and A plus the small products,
+        made once per (context, public-matrix object and content version) and kept while this trapdoor lives."""
+        key = params.ctx_raw().value
+        with self._p1_lock:
+            hit = self._replicas.get(key)
+            if hit is not None and hit[2]() is public_matrix and hit[3] == public_matrix.content_version():
+                return hit[0], hit[1]
+        td, a = self.to_params(params), public_matrix.to_params(params)
+        with self._p1_lock:
+            self._replicas[key] = (td, a, weakref.ref(public_matrix), public_matrix.content_version())
+        return td, a
 
     def to_params(self, params) -> "GpuDCRTTrapdoor":
         """Replica of the trapdoor on another device context: two peer copies (R, E) and the small products
@@ -152,6 +169,37 @@ class GpuDCRTTrapdoor:
         return isinstance(other, GpuDCRTTrapdoor) and self.r == other.r and self.e == other.e
 
     __hash__ = None
+
+
+WORKER_DNUM = 0x5700  # dnum of worker contexts: a context's identity is (ring, moduli, base, devices, dnum)
+_worker_params_cache: dict = {}
+_worker_params_lock = threading.Lock()
+
+
+def preimage_workers() -> int:
+    """`MXX_PREIMAGE_WORKERS` (default 4; 1 = off): worker contexts per device for requests that do not share a trapdoor"""
+    import os
+
+    try:
+        return max(1, min(8, int(os.environ.get("MXX_PREIMAGE_WORKERS", "4"))))
+    except ValueError:
+        return 4
+
+
+def worker_params(params, k: int):
+    """the k-th worker context beside `params` (k >= 1): same ring, moduli and device, its own stream and allocator"""
+    from .params import GpuDCRTPolyParams
+
+    key = (params.ctx_raw().value, k)
+    with _worker_params_lock:
+        pw = _worker_params_cache.get(key)
+        if pw is not None and (pw.moduli() != params.moduli() or pw.ring_dimension() != params.ring_dimension()
+                               or pw.base_bits() != params.base_bits() or pw.gpu_ids() != params.gpu_ids()):
+            pw = None  # the handle value was reused by another context
+        if pw is None:
+            pw = GpuDCRTPolyParams(params.ring_dimension(), params.moduli(), params.base_bits(), gpu_ids=params.gpu_ids(), dnum=WORKER_DNUM + k)
+            _worker_params_cache[key] = pw
+        return pw
 
 
 TRAFFIC_BOUND_BYTES = 32 << 20  # tests set it to 0 to run the large-operand assembly at small sizes
@@ -449,11 +497,46 @@ class GpuDCRTPolyTrapdoorSampler:
             by_key: dict = {}
             for pos, (idx, p, td, a, t) in items:
                 by_key.setdefault((id(td), id(a)), []).append((pos, idx, p, td, a, t))
-            for members in by_key.values():
+            groups_ = list(by_key.values())
+            nworkers = min(preimage_workers(), len(groups_))
+            if nworkers <= 1:
+                for members in groups_:
+                    _, _, p, td, a, _ = members[0]
+                    outs = self.preimage_many(p, td, a, [m[5] for m in members], _seeds=[drawn[m[0]] for m in members])
+                    for (pos, idx, *_), x in zip(members, outs):
+                        results[pos] = (idx, x)
+                return
+            # Different trapdoors in ONE context: the reference runs them concurrently on per-(matrix, limb) streams
+            # (rayon over the requests, cuda/src/matrix/MatrixUtils.cu:259-400); a context here has one compute stream, so
+            # the key groups are dealt to worker contexts - the same device, a stream and an allocator of their own
+            # (`worker_params`).  Worker 0 is the requests' own context; the others get device-to-device replicas of
+            # (trapdoor, A), cached on the trapdoor, and copies of their targets; the preimages come back by
+            # device-to-device copies ordered on both streams (`gpupoly_matrix_copy_to_context`).  A small launch-bound
+            # request fills a few percent of the chip, so several in flight overlap on the device.
+            plan = []  # (worker, members, params, trapdoor, A, targets) with every input already in the worker's context
+            for g_i, members in enumerate(groups_):
+                w = g_i % nworkers
                 _, _, p, td, a, _ = members[0]
-                outs = self.preimage_many(p, td, a, [m[5] for m in members], _seeds=[drawn[m[0]] for m in members])
+                if w == 0:
+                    plan.append((w, members, p, td, a, [m[5] for m in members]))
+                else:
+                    pw = worker_params(p, w)
+                    tdw, aw = td.replica_for(pw, a)
+                    plan.append((w, members, pw, tdw, aw, [m[5].to_params(pw) for m in members]))
+            outs_by_group = [None] * len(plan)
+
+            def work(w):
+                for g_i, (ww, members, pw, tdw, aw, targets) in enumerate(plan):
+                    if ww == w:
+                        outs_by_group[g_i] = self.preimage_many(pw, tdw, aw, targets, _seeds=[drawn[m[0]] for m in members])
+
+            with ThreadPoolExecutor(max_workers=nworkers) as pool:
+                for f in [pool.submit(work, w) for w in range(nworkers)]:
+                    f.result()
+            for (w, members, *_), outs in zip(plan, outs_by_group):
+                p = members[0][2]
                 for (pos, idx, *_), x in zip(members, outs):
-                    results[pos] = (idx, x)
+                    results[pos] = (idx, x if w == 0 else x.to_params(p))
 
         if len(groups) <= 1:
             for items in groups.values():

@@ -31,6 +31,8 @@ def recorded_full_line():
                              "kernel_ms": 1.2345, "d2h_ms": 2.3456, "pcie_GBps": 26.1234, "host_ms": 0.1234}
     full["gate_batch"] = {"ms_per_step": 0.082123, "value": 195123.4, "unit": "products/s", "roofline": {"frac": 0.2123},
                           "loop_ms": 0.463123, "speedup_vs_loop": 5.64123}
+    full["preimage_mixed_keys"] = {"ms_per_step": 2.1234, "value": 30123.4, "unit": "preimages/s", "roofline": {"frac": None},
+                                   "requests_in_flight": 16, "loop_ms": 4.81234, "speedup_vs_loop": 2.2661}
     full["sustained"] = {"steps": 8621, "seconds": 5.0123456, "ms_per_step": 0.58141234, "value": 6191234.5}
     full["roofline"]["counters_stale"] = False
     for blk in (full["preimage"], full["preimage_m3b"], full["chain_m4"], full["chain_m4_batched"]):
@@ -59,8 +61,8 @@ def test_short_line_fits_the_drivers_tail_and_keeps_the_contract_keys():
     assert line["value"] == pytest.approx(full["value"], rel=1e-6) and line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
     # one record per BASELINE configuration (+ the three the round-4 review asked for, + the batched chain)
     assert set(line["configs"]) == {"m1_ntt_mul", "m2b_product", "m2b_decompose", "m2b_mul_decompose", "m3a_preimage",
-                                    "m3a_reference_sequence", "m3b_preimage", "m4_chain", "m4_chain_batched", "compact_bytes",
-                                    "gate_batch"}
+                                    "m3a_reference_sequence", "m3b_preimage", "m4_chain", "m4_chain_batched", "m4_mixed_keys",
+                                    "compact_bytes", "gate_batch"}
     for name, rec in line["configs"].items():
         assert rec["ms_per_step"] and rec["value"] and rec["unit"], name
     assert line["configs"]["m3a_preimage"]["frac_useful"] == 0.3123

@@ -306,3 +306,38 @@ def test_public_matrix_cache_follows_in_place_writes(gpu, oracle):
     assert A.content_version() > v1
     td.clear_public_matrix_cache()
     assert td._stacked is None
+
+
+@pytest.mark.parametrize("workers", ["1", "3"])
+def test_requests_with_different_trapdoors_overlap_on_worker_contexts(gpu, oracle, monkeypatch, workers):
+    """one context, several trapdoors (the GGH15 levels): key groups are dealt to worker contexts on the same device (a
+    stream and an allocator each, replicas of (trapdoor, A) by device-to-device copies); every request still gets the
+    matrix it would get alone, in the context it named, in request order"""
+    from mxx_amd import trapdoor as tdmod
+    from mxx_amd.sampler import seed_source
+
+    monkeypatch.setenv("MXX_PREIMAGE_WORKERS", workers)
+    n, depth, bits, base, d = 256, 3, 51, 17, 2
+    p = make_params(gpu, oracle, n, depth, bits, base)
+    keys = [trapdoor_and_oracle(gpu, oracle, p, n, base, d, seed_bytes(20 + j)) for j in range(3)]
+    sampler = keys[0][0]
+    us = gpu.GpuDCRTPolyUniformSampler()
+    reqs = []
+    for j in range(7):
+        _, td, A, _ = keys[j % 3]
+        reqs.append((j, p, td, A, us.sample_uniform(p, d, 1 + j % 3, gpu.DistType.FinRingDist())))
+    draws = [seed_bytes(400 + i) for i in range(21)]
+    with seed_source(draws):
+        out = sampler.preimage_batched_sharded(reqs)
+    with seed_source(draws):
+        want = [sampler.preimage(pp, t_, a_, u_) for _, pp, t_, a_, u_ in reqs]
+    assert [i for i, _ in out] == list(range(7))
+    for (_, x), w, (_, _, _, a_, u_) in zip(out, want, reqs):
+        assert x.params.ctx_raw().value == p.ctx_raw().value and x == w and a_ * x == u_
+    if workers != "1":
+        pw = tdmod.worker_params(p, 1)
+        assert pw.ctx_raw().value != p.ctx_raw().value and pw.ctx().device() == p.ctx().device()
+        td1 = keys[1][1]
+        assert pw.ctx_raw().value in td1._replicas  # the second key group ran on worker 1, on replicas
+        r_w = td1._replicas[pw.ctx_raw().value][0].r
+        assert r_w.params is pw and np.array_equal(r_w.to_rns(), td1.r.to_rns())
