@@ -1417,7 +1417,7 @@ def mixed_keys_block(mx, device, keys=8, per_key=2, reps=8):
     cols = 4 * len(reqs)
     return {"metric": "trapdoor_preimages_per_s", "value": cols / (many_ms * 1e-3), "unit": "preimages/s", "ms_per_step": many_ms,
             "config": {"workload": f"one preimage_batched_sharded call: {keys} trapdoors x {per_key} requests of 4 columns, n=256, L=12 (51-bit), "
-                                   "d=2; key groups on 4 worker contexts of the device"},
+                                   "d=2; key groups dealt to 4 worker contexts (streams) of the device by one host thread"},
             "requests_in_flight": len(reqs), "loop_ms": one_ms, "speedup_vs_loop": one_ms / many_ms,
             "roofline": {"bound": "hbm", "frac": None, "note": "launch- and latency-bound; the figure of merit is the speed-up over one stream"}}
 

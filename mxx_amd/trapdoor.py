@@ -512,7 +512,8 @@ class GpuDCRTPolyTrapdoorSampler:
             # (`worker_params`).  Worker 0 is the requests' own context; the others get device-to-device replicas of
             # (trapdoor, A), cached on the trapdoor, and copies of their targets; the preimages come back by
             # device-to-device copies ordered on both streams (`gpupoly_matrix_copy_to_context`).  A small launch-bound
-            # request fills a few percent of the chip, so several in flight overlap on the device.
+            # request fills a few percent of the chip, so several in flight overlap on the device (1.5x here; the host's issue
+            # rate bounds it).
             plan = []  # (worker, members, params, trapdoor, A, targets) with every input already in the worker's context
             for g_i, members in enumerate(groups_):
                 w = g_i % nworkers
@@ -523,16 +524,12 @@ class GpuDCRTPolyTrapdoorSampler:
                     pw = worker_params(p, w)
                     tdw, aw = td.replica_for(pw, a)
                     plan.append((w, members, pw, tdw, aw, [m[5].to_params(pw) for m in members]))
-            outs_by_group = [None] * len(plan)
-
-            def work(w):
-                for g_i, (ww, members, pw, tdw, aw, targets) in enumerate(plan):
-                    if ww == w:
-                        outs_by_group[g_i] = self.preimage_many(pw, tdw, aw, targets, _seeds=[drawn[m[0]] for m in members])
-
-            with ThreadPoolExecutor(max_workers=nworkers) as pool:
-                for f in [pool.submit(work, w) for w in range(nworkers)]:
-                    f.result()
+            # ONE host thread issues the groups, dealt round-robin to the worker contexts: no ABI call on this path waits
+            # for the device, so the streams fill side by side.  (A host thread per worker was measured too: the Python
+            # threads pass the interpreter lock back and forth - 3.21 ms against 2.98 from one thread, 4.49 on one stream,
+            # for 8 keys x 2 requests on the M4 ring, tools/time_mixed_keys.py.  A Rust host has no such lock.)
+            outs_by_group = [self.preimage_many(pw, tdw, aw, targets, _seeds=[drawn[m[0]] for m in members])
+                             for _, members, pw, tdw, aw, targets in plan]
             for (w, members, *_), outs in zip(plan, outs_by_group):
                 p = members[0][2]
                 for (pos, idx, *_), x in zip(members, outs):
