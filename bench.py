@@ -974,8 +974,12 @@ def load_counters(workload: str, current_hashes=None):
 
         current_hashes = codeobj.kernel_isa_hashes()
     rec["file"] = f"profiles/{name}"
+    versioned = any(k.get("isa_hash") for k in (rec.get("kernels") or {}).values())
     for base, k in (rec.get("kernels") or {}).items():
-        k["stale"] = k.get("isa_hash") is None or k["isa_hash"] != current_hashes.get(base)
+        if versioned and base.startswith("__amd_rocclr"):
+            k["stale"] = False  # the runtime's own copy / fill kernels: not part of libgpupoly, nothing to compare
+        else:
+            k["stale"] = k.get("isa_hash") is None or k["isa_hash"] != current_hashes.get(base)
     rec["stale_kernels"] = sorted(b for b, k in (rec.get("kernels") or {}).items() if k["stale"])
     return rec
 

@@ -159,6 +159,8 @@ def test_committed_counter_records_match_the_library_or_are_flagged():
         if rec is None:
             continue
         for base, k in rec["kernels"].items():
+            if base.startswith("__amd_rocclr"):
+                continue  # the HIP runtime's copy kernels
             assert k["stale"] == (k.get("isa_hash") is None or k["isa_hash"] != cur.get(base))
     mix = bench.load_valu_mix(cur)
     for base, k in mix.items():
