@@ -1448,7 +1448,7 @@ def _cpu_short(cb):
     if not cb:
         return None
     out = {"value": sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind", "port"),
-           "label": "CPU restatement (oracle/, not OpenFHE)", "sample": (cb.get("sample") or "")[:96]}
+           "label": "CPU restatement (oracle/, not OpenFHE)", "sample": (cb.get("sample") or "")[:60]}
     one = cb.get("one_core") or {}
     if one.get("value") is not None:
         out["one_core_value"] = sig(one["value"])
@@ -1463,17 +1463,20 @@ def _config_record(blk):
     cb = blk.get("cpu_baseline") or {}
     rec = {"ms_per_step": sig(blk.get("ms_per_step")), "value": sig(blk.get("value")), "unit": blk.get("unit"),
            "frac": rf.get("frac")}
-    for key in ("frac_hbm_bytes_only", "frac_useful", "lane_utilisation", "counters_stale"):
+    for key, short in (("frac_hbm_bytes_only", "frac_hbm_bytes_only"), ("frac_useful", "frac_useful"), ("lane_utilisation", "lanes")):
         if rf.get(key) is not None:
-            rec[key] = rf[key]
+            rec[short] = rf[key]
+    if rf.get("counters_stale"):  # only when true: the counted floors / traffic were NOT used
+        rec["counters_stale"] = True
     if rf.get("traffic") and (rf.get("algorithmic_bytes_per_call") or rf.get("algorithmic_bytes_per_launch")):
-        rec["traffic_over_algorithmic"] = sig(rf["traffic"] / (rf.get("algorithmic_bytes_per_call") or rf["algorithmic_bytes_per_launch"]), 4)
+        rec["traffic_x"] = sig(rf["traffic"] / (rf.get("algorithmic_bytes_per_call") or rf["algorithmic_bytes_per_launch"]), 4)  # counted HBM bytes / algorithmic bytes
     if blk.get("kernel_launches_per_step") is not None:
-        rec["launches_per_step"] = blk["kernel_launches_per_step"]
-    for key in ("requests_in_flight", "speedup_vs_one_request", "payload_bytes", "kernel_ms", "d2h_ms", "pcie_GBps", "host_ms",
-                "speedup_vs_loop", "loop_ms", "vs_extension_sequence"):
+        rec["launches"] = blk["kernel_launches_per_step"]
+    for key, short in (("requests_in_flight", "requests"), ("speedup_vs_one_request", "speedup"), ("payload_bytes", "payload_bytes"),
+                       ("kernel_ms", "kernel_ms"), ("d2h_ms", "d2h_ms"), ("pcie_GBps", "pcie_GBps"), ("speedup_vs_loop", "speedup_vs_loop"),
+                       ("loop_ms", "loop_ms"), ("vs_extension_sequence", "vs_extension_sequence")):
         if blk.get(key) is not None:
-            rec[key] = sig(blk[key])
+            rec[short] = sig(blk[key], 4)
     if cb.get("value") is not None:
         rec["cpu_value"], rec["cpu_cores"] = sig(cb["value"]), cb.get("cores")
     return rec
@@ -1534,7 +1537,7 @@ def short_line(full):
             configs[name] = _config_record(full[key])
     s8 = (full.get("preimage") or {}).get("shard_of_8")
     if s8 and configs.get("m3a_preimage"):
-        configs["m3a_preimage"]["predicted_strong_eff_at_8"] = s8.get("predicted_strong_scaling_efficiency_at_8")
+        configs["m3a_preimage"]["strong_eff8_predicted"] = s8.get("predicted_strong_scaling_efficiency_at_8")
     iu = full.get("independent_units")
     if iu:
         line["independent_units"] = {"value": sig(iu.get("value")), "ms_per_step": sig(iu.get("ms_per_step")), "scaling": "weak"}
@@ -1549,7 +1552,7 @@ def short_line(full):
         pex = (full.get("preimage") or {}).get("exchange")
         if pex and pex is not ex:
             line["exchange"]["preimage_self_validated"] = pex.get("self_validated")
-    line["detail"] = "bench_detail.json (also on stderr)"
+    line["detail"] = "bench_detail.json"
     # never exceed the limit: drop the optional parts, least important first
     for victim in ("detail", "sustained", "independent_units"):
         if len(json.dumps(line)) <= SHORT_LINE_LIMIT:

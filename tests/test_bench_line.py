@@ -66,7 +66,8 @@ def test_short_line_fits_the_drivers_tail_and_keeps_the_contract_keys():
     for name, rec in line["configs"].items():
         assert rec["ms_per_step"] and rec["value"] and rec["unit"], name
     assert line["configs"]["m3a_preimage"]["frac_useful"] == 0.3123
-    assert line["configs"]["m4_chain_batched"]["requests_in_flight"] == 16
+    assert line["configs"]["m4_chain_batched"]["requests"] == 16 and "sustained" in line and "detail" in line
+    assert "counters_stale" not in line["configs"]["m3a_preimage"]  # reported only when true
     assert line["configs"]["m1_ntt_mul"]["ntt_frac"] == full["kernels"]["ntt_forward"]["frac_of_hbm_peak"]
 
 
