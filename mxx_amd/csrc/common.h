@@ -49,6 +49,7 @@ struct EnvSwitches {
     int sampler_fill_every = 0;   // MXX_HIP_SAMPLER_FILL_EVERY = 1..8: keystream refill cadence of the Gaussian lane kernels in checkpoints (0 = per kernel default)
     bool ntt64_int = false;       // MXX_HIP_NTT64=int: 64-bit words keep the integer butterflies (A/B, tests)
     int ntt_phase = 0;            // MXX_HIP_NTT_PHASE: phase mask of the forward 2^14 transform, GPUPOLY_PHASE_TIMING builds only (ntt14.h)
+    bool serde_general = false;   // MXX_HIP_SERDE=general: compact store always through the kernels that carry the general Garner path (tests, A/B)
     bool rng_compat = false;      // MXX_HIP_RNG_COMPAT=reference: sample_distribution* keyed exactly as the reference's device RNG (sampling.hip)
     void load();
 };

@@ -283,6 +283,7 @@ void EnvSwitches::load() {
     if (const char *e = std::getenv("MXX_HIP_P1")) p1_simple = e[0] == 's';
     if (const char *e = std::getenv("MXX_HIP_NTT64")) ntt64_int = e[0] == 'i';
     if (const char *e = std::getenv("MXX_HIP_RNG_COMPAT")) rng_compat = e[0] == 'r';
+    if (const char *e = std::getenv("MXX_HIP_SERDE")) serde_general = e[0] == 'g';
     if (const char *e = std::getenv("MXX_HIP_SAMPLER_PER_LANE")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 4096) sampler_per_lane = v;

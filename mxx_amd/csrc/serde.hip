@@ -190,6 +190,132 @@ __device__ __forceinline__ uint32_t reconstruct_centered(const W *__restrict__ s
     return 0;
 }
 
+// ---- fast-path-only forms ----------------------------------------------------------------------------------------------
+// The matrices that get serialised (preimages, trapdoors, Gaussian-sized keys) never leave the two fast paths of
+// reconstruct_centered, but kernels that also carry the general Garner path pay for it in registers (102 / 73 VGPRs, the
+// word array indexed dynamically in scratch): 0.45 + 0.66 ms for an M3A preimage against 0.09 ms of reading it.  These
+// forms hold ONLY the fast paths - a coefficient is |x| < q_0 / 2 or |x| < q_0 q_1 / 2, checked against every further
+// limb - and raise a flag for anything else; the host then reruns the general kernels (never, for the matrices above).
+template <typename W, int ML>
+__device__ __forceinline__ bool reconstruct_small(const W *__restrict__ src, size_t poly, uint32_t i, uint32_t N,
+                                                  const SerdeConsts &sc, const uint64_t *__restrict__ garner,
+                                                  size_t garner_stride, const LimbConst *__restrict__ limbs,
+                                                  uint64_t &mag_lo, uint64_t &mag_hi, bool &negative) {
+    static_assert(ML <= 16, "fast forms are unrolled over the limbs");
+    typedef typename Wide<W>::type D;
+    const int L = sc.limbs;
+    uint64_t res[ML];
+#pragma unroll
+    for (int k = 0; k < ML; ++k)
+        if (k < L) res[k] = static_cast<uint64_t>(src[(poly * L + k) * N + i]);
+    const uint64_t q0 = sc.q[0];
+    {
+        const bool neg0 = res[0] > (q0 >> 1);
+        const uint64_t mag = neg0 ? q0 - res[0] : res[0];
+        bool small = true;
+#pragma unroll
+        for (int k = 1; k < ML; ++k)
+            if (k < L) {
+                const uint64_t qk = sc.q[k];
+                small = small && mag < qk && res[k] == (neg0 ? qk - mag : mag);
+            }
+        if (small) {
+            mag_lo = mag;
+            mag_hi = 0;
+            negative = neg0 && mag != 0;
+            return true;
+        }
+    }
+    if (L < 2) return false;
+    const uint64_t q1 = sc.q[1];
+    const uint64_t r0m = res[0] >= q1 ? res[0] % q1 : res[0];
+    const uint64_t dd = res[1] >= r0m ? res[1] - r0m : res[1] + q1 - r0m;
+    const uint64_t v1 = static_cast<uint64_t>(barrett_reduce(static_cast<D>(dd) * static_cast<D>(garner[garner_stride]), static_cast<W>(q1), limbs[1].mu, limbs[1].kbits));
+    const D q01 = static_cast<D>(q0) * q1;
+    const D val = static_cast<D>(res[0]) + static_cast<D>(v1) * q0;
+    const bool neg2 = val > (q01 >> 1);
+    const D mag2 = neg2 ? q01 - val : val;
+    bool ok = true;
+#pragma unroll
+    for (int k = 2; k < ML; ++k)
+        if (k < L) {
+            const uint64_t qk = sc.q[k];
+            const uint32_t kb = limbs[k].kbits;
+            const bool fits = 2 * kb >= 8 * sizeof(D) || (mag2 >> (2 * kb)) == 0;
+            const uint64_t r = static_cast<uint64_t>(barrett_reduce(mag2, static_cast<W>(qk), limbs[k].mu, kb));
+            ok = ok && fits && res[k] == ((neg2 && r) ? qk - r : r);
+        }
+    mag_lo = static_cast<uint64_t>(mag2);
+    mag_hi = 0;
+    if constexpr (sizeof(D) > 8) mag_hi = static_cast<uint64_t>(mag2 >> 64);
+    negative = neg2 && mag2 != 0;
+    return ok;
+}
+
+template <typename W, int ML>
+__global__ void __launch_bounds__(256) compact_maxbits_fast_kernel(const W *__restrict__ src, size_t polys, uint32_t N, SerdeConsts sc,
+                                            const uint64_t *__restrict__ garner, size_t garner_stride,
+                                            const LimbConst *__restrict__ limbs, unsigned int *__restrict__ max_and_flag) {
+    const size_t idx = item_index();
+    unsigned int bits = 0;
+    if (idx < polys * N) {
+        uint64_t lo, hi;
+        bool neg;
+        if (reconstruct_small<W, ML>(src, idx / N, static_cast<uint32_t>(idx % N), N, sc, garner, garner_stride, limbs, lo, hi, neg))
+            bits = hi ? 128u - static_cast<uint32_t>(__clzll(hi)) : (lo ? 64u - static_cast<uint32_t>(__clzll(lo)) : 0u);
+        else
+            max_and_flag[1] = 1u;  // some coefficient needs the general path: the host reruns with the general kernels
+    }
+    for (int off = 32; off > 0; off >>= 1) bits = max(bits, __shfl_down(bits, off));
+    if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(max_and_flag, __ATOMIC_RELAXED)) atomicMax(max_and_flag, bits);
+}
+
+// width <= 130 here (|x| below 2^102 at most); the block's 8 * width payload words are assembled in LDS as in the general form
+template <typename W, int ML>
+__global__ void __launch_bounds__(256) compact_pack_fast_kernel(const W *__restrict__ src, size_t polys, uint32_t N, SerdeConsts sc,
+                                         const uint64_t *__restrict__ garner, size_t garner_stride,
+                                         const LimbConst *__restrict__ limbs, uint32_t width, uint32_t *__restrict__ payload_words,
+                                         size_t payload_word_count) {
+    extern __shared__ uint32_t pack_words[];
+    const size_t idx = item_index();
+    const size_t block_first = idx - threadIdx.x;
+    const uint32_t nwords = 8u * width;
+    for (uint32_t w = threadIdx.x; w < nwords; w += 256) pack_words[w] = 0;
+    __syncthreads();
+    if (idx < polys * N) {
+        uint64_t lo, hi;
+        bool neg;
+        (void)reconstruct_small<W, ML>(src, idx / N, static_cast<uint32_t>(idx % N), N, sc, garner, garner_stride, limbs, lo, hi, neg);
+        // 192 bits: |x| in words 0..1, the sign bit at width - 1 (at most bit 129)
+        uint64_t x0 = lo, x1 = hi, x2 = 0;
+        if (neg) {
+            const uint32_t sb = width - 1;
+            const uint64_t bit = 1ull << (sb & 63);
+            if (sb < 64) x0 |= bit;
+            else if (sb < 128) x1 |= bit;
+            else x2 |= bit;
+        }
+        const uint32_t base = threadIdx.x * width;
+        uint32_t done = 0;
+        while (done < width) {
+            const uint32_t bit = base + done;
+            const uint32_t off = bit & 31u;
+            const uint32_t take = min(32u - off, width - done);
+            const uint32_t wi = done >> 6, bo = done & 63u;
+            const uint64_t cur = wi == 0 ? x0 : (wi == 1 ? x1 : x2), nxt = wi == 0 ? x1 : (wi == 1 ? x2 : 0ull);
+            uint64_t chunk = cur >> bo;
+            if (bo + take > 64) chunk |= nxt << (64 - bo);
+            const uint32_t val = static_cast<uint32_t>(chunk & ((take == 32) ? 0xffffffffull : ((1ull << take) - 1)));
+            if (val) atomicOr(&pack_words[bit >> 5], val << off);
+            done += take;
+        }
+    }
+    __syncthreads();
+    const size_t first_word = block_first / 256 * nwords;
+    for (uint32_t w = threadIdx.x; w < nwords; w += 256)
+        if (first_word + w < payload_word_count) payload_words[first_word + w] = pack_words[w];
+}
+
 template <typename W, int ML>
 __global__ void compact_maxbits_kernel(const W *__restrict__ src, size_t polys, uint32_t N, SerdeConsts sc,
                                        const uint64_t *__restrict__ garner, size_t garner_stride,
@@ -367,25 +493,50 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
     const dim3 blocks = item_grid(coeffs, 256);
     const size_t gstride = static_cast<size_t>(ctx->limb_count);
     CtxBlock max_block(ctx);
-    if (max_block.alloc(sizeof(unsigned int))) return 1;
+    if (max_block.alloc(2 * sizeof(unsigned int))) return 1;  // [0] running maximum of the widths, [1] "needs the general path"
     void *const d_max = max_block.ptr;
-    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned int), ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_max, 0, 2 * sizeof(unsigned int), ctx->stream));
+    // fast-path-only kernels first (up to 16 limbs): preimages, trapdoors and Gaussian-sized keys never leave them
+    bool fast = sc.limbs <= 16 && !ctx->env.serde_general;
+    unsigned int h_mf[2] = {0, 0};
+    if (fast) {
+#define FAST_MAXBITS(WT, ML)                                                                                             \
+    MXX_LAUNCH((compact_maxbits_fast_kernel<WT, ML>), blocks, dim3(256), 0, ctx->stream, static_cast<const WT *>(mat->data), polys, N, sc, \
+               ctx->d_garner, gstride, ctx->d_limbs, static_cast<unsigned int *>(d_max))
+        if (ctx->wide) {
+            if (sc.limbs <= 8) FAST_MAXBITS(uint64_t, 8);
+            else FAST_MAXBITS(uint64_t, 16);
+        } else {
+            if (sc.limbs <= 8) FAST_MAXBITS(uint32_t, 8);
+            else FAST_MAXBITS(uint32_t, 16);
+        }
+#undef FAST_MAXBITS
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_mf, d_max, sizeof(h_mf), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (h_mf[1]) {  // a coefficient beyond the fast paths: start over with the general kernels
+            fast = false;
+            HIP_TRY(hipMemsetAsync(d_max, 0, 2 * sizeof(unsigned int), ctx->stream));
+        }
+    }
 #define SERDE_LAUNCH(KERNEL, WT, ...)                                                                                  \
     do {                                                                                                               \
         if (sc.limbs <= 8) MXX_LAUNCH((KERNEL<WT, 8>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);         \
         else if (sc.limbs <= 16) MXX_LAUNCH((KERNEL<WT, 16>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);  \
         else MXX_LAUNCH((KERNEL<WT, 64>), blocks, dim3(256), 0, ctx->stream, __VA_ARGS__);                      \
     } while (0)
-    if (ctx->wide)
-        SERDE_LAUNCH(compact_maxbits_kernel, uint64_t, static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner,
-                     gstride, ctx->d_limbs, static_cast<unsigned int *>(d_max));
-    else
-        SERDE_LAUNCH(compact_maxbits_kernel, uint32_t, static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner,
-                     gstride, ctx->d_limbs, static_cast<unsigned int *>(d_max));
-    HIP_TRY(hipGetLastError());
-    unsigned int h_max = 0;
-    HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned int h_max = h_mf[0];
+    if (!fast) {
+        if (ctx->wide)
+            SERDE_LAUNCH(compact_maxbits_kernel, uint64_t, static_cast<const uint64_t *>(mat->data), polys, N, sc, ctx->d_garner,
+                         gstride, ctx->d_limbs, static_cast<unsigned int *>(d_max));
+        else
+            SERDE_LAUNCH(compact_maxbits_kernel, uint32_t, static_cast<const uint32_t *>(mat->data), polys, N, sc, ctx->d_garner,
+                         gstride, ctx->d_limbs, static_cast<unsigned int *>(d_max));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     const unsigned int width = h_max == 0 ? 0 : h_max + 1;
     if (width > 0xffffu) return set_error("centered max coeff bits exceed u16 range in gpu_matrix_store_compact_bytes");
     const unsigned int bytes_per_coeff = (width + 7) / 8;
@@ -419,13 +570,25 @@ extern "C" int gpu_matrix_store_compact_bytes(GpuMatrix *mat, uint8_t *payload_o
         else if (sc.limbs <= 16) PACK_LAUNCH(WT, 16, LDSF); \
         else PACK_LAUNCH(WT, 64, LDSF);               \
     } while (0)
-        if (ctx->wide) {
+#define FAST_PACK(WT, ML)                                                                                                \
+    MXX_LAUNCH((compact_pack_fast_kernel<WT, ML>), blocks, dim3(256), pack_lds, ctx->stream, static_cast<const WT *>(mat->data), polys, N, sc, \
+               ctx->d_garner, gstride, ctx->d_limbs, width, static_cast<uint32_t *>(d_payload), word_count)
+        if (fast && in_lds) {
+            if (ctx->wide) {
+                if (sc.limbs <= 8) FAST_PACK(uint64_t, 8);
+                else FAST_PACK(uint64_t, 16);
+            } else {
+                if (sc.limbs <= 8) FAST_PACK(uint32_t, 8);
+                else FAST_PACK(uint32_t, 16);
+            }
+        } else if (ctx->wide) {
             if (in_lds) PACK_BY_LIMBS(uint64_t, true);
             else PACK_BY_LIMBS(uint64_t, false);
         } else {
             if (in_lds) PACK_BY_LIMBS(uint32_t, true);
             else PACK_BY_LIMBS(uint32_t, false);
         }
+#undef FAST_PACK
 #undef PACK_BY_LIMBS
 #undef PACK_LAUNCH
         HIP_TRY(hipGetLastError());

@@ -108,3 +108,67 @@ def test_mul_decompose_extension_matches_chunked(gpu, oracle):
     out = gpu.GpuDCRTPolyMatrix.new_empty(p, 2, 5)
     _ffi.check_status(_ffi.lib().gpupoly_matrix_mul_decompose(out.raw, S.raw, B.raw, base), "gpupoly_matrix_mul_decompose")
     assert out == want
+
+
+def _signed_matrix(rng, shape, n, moduli, magnitude):
+    v = rng.integers(-magnitude, magnitude + 1, size=shape + (n,), dtype=np.int64)
+    return v, np.stack([np.mod(v, q).astype(np.uint64) for q in moduli], axis=-2)
+
+
+@pytest.mark.parametrize("n,depth,bits,magnitude", [(256, 5, 24, 2 ** 22), (256, 5, 24, 2 ** 40), (256, 10, 24, 2 ** 45), (128, 12, 51, 2 ** 49),
+                                                      (128, 12, 51, 2 ** 62), (64, 3, 51, 2 ** 62)])
+def test_compact_store_fast_forms_equal_the_general_kernels_and_the_oracle(gpu, oracle, hip_env, n, depth, bits, magnitude):
+    """round 5: the store runs fast-path-only kernels first (|x| < q_0 / 2, |x| < q_0 q_1 / 2, every further limb checked) and
+    falls back to the kernels with the general Garner path when a coefficient raises the flag.  Both forms, the
+    LDS-assembled pack included, against the CPU packing - magnitudes in the one-limb range, the two-limb range (24- and
+    51-bit limbs, one and two words), and a matrix whose single large entry forces the rerun."""
+    p = make_params(gpu, oracle, n, depth, bits, 12)
+    moduli = p.moduli()
+    rng = np.random.default_rng(depth * 1000 + bits)
+    v, coeff = _signed_matrix(rng, (3, 4), n, moduli, magnitude)
+    want_payload, want_bits, want_bpc = oracle.compact_payload(coeff, moduli)
+    blobs = []
+    for mode in ("fast", "general"):
+        if mode == "general":
+            hip_env.set("MXX_HIP_SERDE", "general")
+        m = gpu.GpuDCRTPolyMatrix.from_rns(p, coeff, False)
+        blob = m.to_compact_bytes()
+        _, _, _, _, _, max_bits, bpc, payload = _payload_of(blob)
+        assert (max_bits, bpc) == (want_bits, want_bpc) and payload == want_payload, mode
+        assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, blob) == m
+        blobs.append(blob)
+    assert blobs[0] == blobs[1]
+    hip_env.unset("MXX_HIP_SERDE")
+    # one coefficient beyond both fast paths (a uniform residue vector): the flag sends the call to the general kernels
+    big = coeff.copy()
+    big[1, 2, :, 7] = rand_matrix(oracle, 7, 1, 1, moduli, n)[0, 0, :, 7]
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, big, False)
+    blob = m.to_compact_bytes()
+    wp, wb, wc = oracle.compact_payload(big, moduli)
+    _, _, _, _, _, max_bits, bpc, payload = _payload_of(blob)
+    assert (max_bits, bpc) == (wb, wc) and payload == wp
+    assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, blob) == m
+
+
+def test_compact_view_is_the_same_bytes_without_a_host_copy(gpu, oracle):
+    """`into_compact_view`: the framed payload in this thread's pinned staging buffer (valid until the next call); a buffer that
+    is too small for the payload is retried with the length the library reports"""
+    from mxx_amd import matrix as M
+
+    n = 1024
+    p = make_params(gpu, oracle, n, 3, 24, 12)
+    moduli = p.moduli()
+    rng = np.random.default_rng(9)
+    _, small = _signed_matrix(rng, (2, 3), n, moduli, 5)
+    m = gpu.GpuDCRTPolyMatrix.from_rns(p, small, True)
+    want = m.to_compact_bytes()
+    view = m.clone().into_compact_view()
+    assert isinstance(view, memoryview) and bytes(view) == want
+    # uniform residues need bits(Q) + 1 per coefficient: more than the first attempt's buffer
+    uni = rand_matrix(oracle, 33, 4, 6, moduli, n)
+    u = gpu.GpuDCRTPolyMatrix.from_rns(p, uni, False)
+    before = M._pinned_capacity()
+    blob = bytes(u.clone().into_compact_view())
+    assert gpu.GpuDCRTPolyMatrix.from_compact_bytes(p, blob) == u
+    assert _payload_of(blob)[7] == oracle.compact_payload(uni, moduli)[0]
+    assert M._pinned_capacity() >= max(before, len(blob))
