@@ -741,7 +741,7 @@ class M4Batched(M4):
     call over the concatenated operands (G^-1 works column by column)."""
 
     name = "m4_batched"
-    requests = 16
+    requests = int(os.environ.get("MXX_BENCH_M4_REQUESTS", "16"))  # the default line reports 16 in flight
 
     def setup(self):
         super().setup()
