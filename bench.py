@@ -1496,6 +1496,9 @@ def short_line(full):
                       "sharding": (cfg.get("sharding") or "")[:100]}
     if full.get("gather") is not None:
         line["gather"] = full["gather"]
+    og = full.get("other_gather")
+    if og:  # N > 1: the same K steps under the other exchange policy (per step <-> once per region)
+        line["other_gather"] = {"gather": og.get("gather"), "value": sig(og.get("value")), "ms_per_step": sig(og.get("ms_per_step"))}
     rep = full.get("repeats") or {}
     if rep:
         line["median_ms_per_step"] = sig(rep.get("median_ms_per_step"), 6)
@@ -1554,7 +1557,7 @@ def short_line(full):
             line["exchange"]["preimage_self_validated"] = pex.get("self_validated")
     line["detail"] = "bench_detail.json"
     # never exceed the limit: drop the optional parts, least important first
-    for victim in ("detail", "sustained", "independent_units"):
+    for victim in ("detail", "sustained", "other_gather", "independent_units"):
         if len(json.dumps(line)) <= SHORT_LINE_LIMIT:
             break
         line.pop(victim, None)

@@ -90,7 +90,12 @@ def test_short_line_at_n_gpus_carries_the_exchange_verdict():
                         "foreign_blocks_checked_per_rank": [1, 1], "self_validated": True, "distinct_devices": True,
                         "comm_verified_on_distinct_devices_before_this_run": False, "comm_verified_by_this_run": True}
     full["preimage"]["exchange"] = dict(full["exchange"])
+    full["gather"] = "step"
+    full["other_gather"] = {"gather": "lazy", "ms_per_step": 0.0912345, "value": 39458123.4}
+    full["independent_units"] = {"scaling": "weak", "value": 12345678.9, "ms_per_step": 0.5912345, "units_per_step": 7200, "sharding": "x"}
     line = bench.short_line(full)
+    assert line["gather"] == "step" and line["other_gather"] == {"gather": "lazy", "value": 39458000, "ms_per_step": 0.091234}
+    assert line["independent_units"]["scaling"] == "weak" and line["independent_units"]["value"] == 12346000
     assert line["exchange"] == {"ranks_seen": 2, "comm_backend": "torch.distributed 'nccl' (RCCL)", "self_validated": True,
                                 "distinct_devices": True, "comm_verified_by_this_run": True, "preimage_self_validated": True}
     assert line["cpu_baseline"] is None
