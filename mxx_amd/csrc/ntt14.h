@@ -52,8 +52,8 @@ __device__ __forceinline__ void wave_sync() {
 // ADD: the vector `addv` (canonical residues, evaluation order) is added to the result on its way out
 // GPUPOLY_PHASE_TIMING builds only (tools/build_variant.sh phase PHASE_TIMING=1; tools/ab_ntt_phases.sh; the mask comes from
 // MXX_HIP_NTT_PHASE): `phase` switches parts of the kernel off at run time - bit 0: no global loads (synthetic inputs),
-// bit 1: no butterflies, bit 2: no global stores - to time the memory skeleton and the arithmetic separately.  Results
-// are wrong by design in those modes.
+// bit 1: no butterflies, bit 2: no global stores, bit 5: no LDS traffic and no barriers - to time the memory skeleton, the
+// arithmetic and the exchanges separately.  Results are wrong by design in those modes.
 #ifdef GPUPOLY_PHASE_TIMING
 #define NTT14_PHASE(bit) ((phase & (bit)) != 0)
 #else
@@ -88,41 +88,51 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
     for (int grp = 0; grp < 4; ++grp) {
         W *x = xs + (grp & 1) * GROUP_WORDS;
         // transpose through LDS: block (8*grp + m) receives its element `tid`
+        if (!NTT14_PHASE(32)) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) x[m * BLK_PAD + pad64(tid)] = h[8 * grp + m];
-        __syncthreads();
+            for (int m = 0; m < 8; ++m) x[m * BLK_PAD + pad64(tid)] = h[8 * grp + m];
+            __syncthreads();
+        }
         W *xb = x + wave * BLK_PAD;            // from here on this wave owns block B alone
         const uint32_t B = 8u * grp + wave;
         W v[8];
         {   // stages 5,6,7: sets {lane + 64 m}; twiddles are wave-uniform
             const uint32_t base = pad64(lane);  // pad64(lane + 64 m) = pad64(lane) + 72 m
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[base + 72 * m];
+            for (int m = 0; m < 8; ++m) v[m] = NTT14_PHASE(32) ? h[8 * grp + m] : xb[base + 72 * m];  // bit 5: no LDS traffic, no barriers (arithmetic only)
             if (!NTT14_PHASE(2)) {
                 ct_prefold<W, 3, TIGHT>(v, q);
                 ct_network_lazy<W, 3>(v, tw, B, 5, q, twoq);
             }
+            if (!NTT14_PHASE(32)) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) xb[base + 72 * m] = v[m];
+                for (int m = 0; m < 8; ++m) xb[base + 72 * m] = v[m];
+            }
         }
-        wave_sync();
+        if (!NTT14_PHASE(32)) wave_sync();
         {   // stages 8,9,10: sets {64 c + j + 8 m}, c = lane/8, j = lane%8
             const uint32_t c = lane >> 3, j = lane & 7u;
             const uint32_t base = 72 * c + j;  // pad64(64 c + j + 8 m) = 72 c + j + 8 m + 4 (m >> 2)
+            if (!NTT14_PHASE(32)) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m + 4 * (m >> 2)];
+                for (int m = 0; m < 8; ++m) v[m] = xb[base + 8 * m + 4 * (m >> 2)];
+            }
             if (!NTT14_PHASE(2)) {
                 ct_prefold<W, 3, TIGHT>(v, q);
                 ct_network_lazy<W, 3>(v, tw, B * 8u + c, 8, q, twoq);
             }
+            if (!NTT14_PHASE(32)) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) xb[base + 8 * m + 4 * (m >> 2)] = v[m];
+                for (int m = 0; m < 8; ++m) xb[base + 8 * m + 4 * (m >> 2)] = v[m];
+            }
         }
-        wave_sync();
+        if (!NTT14_PHASE(32)) wave_sync();
         {   // stages 11,12,13: 8 contiguous words per lane, then canonical form and out to HBM
             const uint32_t base = pad64(8 * lane);
+            if (!NTT14_PHASE(32)) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = xb[base + m];
+                for (int m = 0; m < 8; ++m) v[m] = xb[base + m];
+            }
             if (!NTT14_PHASE(2)) {
                 ct_prefold<W, 3, TIGHT>(v, q);
                 ct_network_lazy<W, 3>(v, tw, B * 64u + lane, 11, q, twoq);
