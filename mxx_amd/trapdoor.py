@@ -333,7 +333,7 @@ class GpuDCRTPolyTrapdoorSampler:
         sliced and [R; E] concatenated on every call, tp2 is a product of its own, z comes back in EVAL form, R z and E z
         are two products, and the output is assembled with two copy_block + three add_block calls.  Only entry points the
         Rust side binds are used (44 `gpu_*` symbols; no `gpupoly_*` extension).  Same distribution and same seeds ->
-        same residues as `preimage` (tests/test_gpu_surface.py); bench.py times it next to the extension sequence."""
+        same residues as `preimage` (tests/test_gpu_preimage_batch.py); bench.py times it next to the extension sequence."""
         d = public_matrix.row_size()
         target_cols = target.col_size()
         assert target.row_size() == d, "Target matrix should have the same number of rows as the public matrix"
