@@ -1398,6 +1398,7 @@ def mixed_keys_block(mx, device, keys=8, per_key=2, reps=8):
         reqs.append((j, p, td, a, us.sample_uniform(p, 2, 4, mx.DistType.FinRingDist())))
 
     def timed(workers):
+        before = os.environ.get("MXX_PREIMAGE_WORKERS")
         os.environ["MXX_PREIMAGE_WORKERS"] = str(workers)
         try:
             out = None
@@ -1412,7 +1413,10 @@ def mixed_keys_block(mx, device, keys=8, per_key=2, reps=8):
                 ts.append((time.perf_counter() - t0) * 1e3)
             return statistics.median(ts), out
         finally:
-            os.environ.pop("MXX_PREIMAGE_WORKERS", None)
+            if before is None:
+                os.environ.pop("MXX_PREIMAGE_WORKERS", None)
+            else:
+                os.environ["MXX_PREIMAGE_WORKERS"] = before
 
     one_ms, _ = timed(1)
     many_ms, out = timed(4)
