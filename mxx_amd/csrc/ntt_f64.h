@@ -112,6 +112,73 @@ __device__ __forceinline__ uint64_t to_residue(double x, double q, double qinv) 
 __device__ __forceinline__ double raw_f64(uint64_t bits) { return __longlong_as_double(static_cast<long long>(bits)); }
 __device__ __forceinline__ uint64_t f64_raw(double x) { return static_cast<uint64_t>(__double_as_longlong(x)); }
 
+// ---- small rings (2..512 points): one radix-2 stage per barrier, the vector as doubles in LDS ------------------------
+// The rings of the GGH15 chain (n = 256, 51-bit limbs) used the integer kernel of ntt.hip - a 64 x 64 Shoup product per
+// butterfly, ~30 VALU instructions; the same loop on doubles is mulmod's six + the butterfly's two (+ folds).  Bounds in
+// units of q / 4 for the tightest case (51-bit moduli: 15 units, as ELIM of the whole-vector kernels): canonical inputs
+// are at 4; forward 4 -> 8 -> 14, then a fold (2) before every second stage (2 -> 5 -> 10); inverse 4 -> 8, then a fold
+// before every second stage (2 -> 4 -> 8) - the schedule is fixed, so smaller moduli just fold more often than they must.  Same tables and
+// bit-reversed order as every other kernel; outputs canonical, bit-identical to the integer kernel.
+template <bool INV>
+__global__ void small_kernel(uint64_t *__restrict__ data, const TwF *__restrict__ tw_all, const F64Limb *__restrict__ limbs,
+                             uint32_t L, uint32_t logN) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *x = reinterpret_cast<double *>(smem);
+    const uint32_t N = 1u << logN, tid = threadIdx.x, T = blockDim.x;
+    const size_t vec = blockIdx.x;
+    const uint32_t limb = static_cast<uint32_t>(vec % L);
+    const F64Limb lc = limbs[limb];
+    const TwF *tw = tw_all + static_cast<size_t>(limb) * N;
+    uint64_t *g = data + vec * N;
+    for (uint32_t i = tid; i < N; i += T) x[i] = static_cast<double>(g[i]);
+    __syncthreads();
+    if (!INV) {
+        uint32_t logt = logN - 1;
+        for (uint32_t s = 0; s < logN; ++s, --logt) {
+            const uint32_t m = 1u << s, t = 1u << logt;
+            const bool fold_in = s >= 2 && (s & 1u) == 0;
+            for (uint32_t b = tid; b < N / 2; b += T) {
+                const uint32_t i = b >> logt, j = b & (t - 1);
+                const uint32_t lo = (i << (logt + 1)) + j, hi = lo + t;
+                double U = x[lo], V = x[hi];
+                if (fold_in) {
+                    U = fold(U, lc.q, lc.qinv);
+                    V = fold(V, lc.q, lc.qinv);
+                }
+                const double Tm = mulmod(V, tw[m + i], lc.q);
+                x[lo] = U + Tm;
+                x[hi] = U - Tm;
+            }
+            __syncthreads();
+        }
+    } else {
+        uint32_t logt = 0;
+        for (uint32_t s = 0; s < logN; ++s, ++logt) {
+            const uint32_t m = N >> (s + 1), t = 1u << logt;
+            const bool fold_in = (s & 1u) != 0, last = s + 1 == logN;
+            for (uint32_t b = tid; b < N / 2; b += T) {
+                const uint32_t i = b >> logt, j = b & (t - 1);
+                const uint32_t lo = (i << (logt + 1)) + j, hi = lo + t;
+                double X = x[lo], Y = x[hi];
+                if (fold_in) {
+                    X = fold(X, lc.q, lc.qinv);
+                    Y = fold(Y, lc.q, lc.qinv);
+                }
+                const double A = X + Y, D = X - Y;
+                if (last) {  // N^-1 folded into the last stage's two products (m = 1, i = 0)
+                    x[lo] = mulmod(A, lc.n_inv, lc.q);
+                    x[hi] = mulmod(D, lc.last_w, lc.q);
+                } else {
+                    x[lo] = A;
+                    x[hi] = mulmod(D, tw[m + i], lc.q);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < N; i += T) g[i] = to_residue(x[i], lc.q, lc.qinv);
+}
+
 // the transform of one (sub-)vector: `load(e)` supplies residue e (natural order); canonical residues, bit-reversed, to g.
 // PRE > 0 (rings beyond LDS, as ntt_lds.h): the vector has 2^(LOGN + PRE) points, head_kernel did its first PRE stages and
 // left folded doubles; this workgroup transforms sub-vector `sub`, twiddles at stage PRE + s, block (sub << s) + b.

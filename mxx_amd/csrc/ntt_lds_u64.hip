@@ -92,7 +92,27 @@ static int dispatch_f64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_
     }
 }
 
+// rings below 2^10 points with moduli below 2^51: the double-precision form of the generic one-stage-per-barrier kernel
+static int launch_f64_small(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t L, bool inverse) {
+    const uint32_t logN = ctx->logN;
+    const size_t N = size_t(1) << logN;
+    unsigned threads = static_cast<unsigned>(N / 2);
+    if (threads < 64) threads = 64;
+    if (threads > 512) threads = 512;
+    const dim3 grid(static_cast<unsigned>(vectors)), block(threads);
+    const size_t lds = N * sizeof(double);
+    const F64Limb *fl = static_cast<const F64Limb *>(ctx->d_flimbs);
+    if (!inverse)
+        MXX_LAUNCH((nttf::small_kernel<false>), grid, block, lds, ctx->stream, data, static_cast<const TwF *>(ctx->d_twf_fwd), fl, L, logN);
+    else
+        MXX_LAUNCH((nttf::small_kernel<true>), grid, block, lds, ctx->stream, data, static_cast<const TwF *>(ctx->d_twf_inv), fl, L, logN);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_ntt_lds_u64(GpuContext *ctx, uint64_t *data, size_t vectors, uint32_t L, bool inverse) {
+    if (ctx->f64_ok && !ctx->env.ntt64_int && ctx->env.ntt_path <= 1 && ctx->logN >= 1 && ctx->logN < 10 && vectors <= 0x7fffffffull)
+        return launch_f64_small(ctx, data, vectors, L, inverse);
     if (f64_path(ctx) && vectors <= 0x7fffffffull) {
         const int rc = ctx->crt_bits <= 40   ? dispatch_f64<4095>(ctx, data, vectors, L, inverse)
                        : ctx->crt_bits <= 49 ? dispatch_f64<63>(ctx, data, vectors, L, inverse)

@@ -437,7 +437,7 @@ static int upload_tables(GpuContext *ctx, const std::vector<std::vector<uint64_t
     HIP_TRY(hipMalloc(&ctx->d_tw2_inv, 2 * bytes));
     HIP_TRY(hipMemcpy(ctx->d_tw2_fwd, h_pf.data(), 2 * bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tw2_inv, h_pi.data(), 2 * bytes, hipMemcpyHostToDevice));
-    if (sizeof(W) == 8 && ctx->crt_bits <= 51 && N >= 1024) {
+    if (sizeof(W) == 8 && ctx->crt_bits <= 51 && N >= 2) {
         // double-precision tables for ntt_f64.h: {w, w / q} (the quotient of two exactly representable integers is
         // correctly rounded, so the device sees the same bits on every host)
         struct HostTwF { double w, wi; };

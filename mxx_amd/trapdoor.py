@@ -192,13 +192,13 @@ def worker_params(params, k: int):
 
     key = (params.ctx_raw().value, k)
     with _worker_params_lock:
-        pw = _worker_params_cache.get(key)
-        if pw is not None and (pw.moduli() != params.moduli() or pw.ring_dimension() != params.ring_dimension()
-                               or pw.base_bits() != params.base_bits() or pw.gpu_ids() != params.gpu_ids()):
-            pw = None  # the handle value was reused by another context
-        if pw is None:
-            pw = GpuDCRTPolyParams(params.ring_dimension(), params.moduli(), params.base_bits(), gpu_ids=params.gpu_ids(), dnum=WORKER_DNUM + k)
-            _worker_params_cache[key] = pw
+        for dead in [kk for kk, (owner, _) in _worker_params_cache.items() if owner() is None]:
+            del _worker_params_cache[dead]  # the context a worker belonged to is gone: let the worker context go too
+        hit = _worker_params_cache.get(key)
+        if hit is not None and hit[0]() is params.ctx():
+            return hit[1]
+        pw = GpuDCRTPolyParams(params.ring_dimension(), params.moduli(), params.base_bits(), gpu_ids=params.gpu_ids(), dnum=WORKER_DNUM + k)
+        _worker_params_cache[key] = (weakref.ref(params.ctx()), pw)
         return pw
 
 

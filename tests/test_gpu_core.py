@@ -71,7 +71,9 @@ def test_ntt_small_rings(gpu, oracle, hip_env, logn, bits):
     """n = 2..512 (the reference's unit-test rings and BASELINE configs[4]'s n = 256) in both word widths, moduli from 17 to
     61 bits, 63 vectors per call, extreme residues, both directions - against the CPU restatement, default dispatch and
     the forced generic kernel.  (A wave-per-vector kernel for these sizes was built in round 3 and measured slower than
-    the 128-thread LDS kernel - profiles/r03_notes.md - so both dispatches currently land on the same kernel.)"""
+    the 128-thread LDS kernel - profiles/r03_notes.md.)  Round 5: 64-bit words with moduli below 2^51 take the
+    double-precision form of that kernel (nttf::small_kernel) by default; MXX_HIP_NTT64=int and the forced generic path
+    keep the integer one - all three must give the oracle's bits."""
     n = 1 << logn
     depth = 3
     moduli = oracle.gen_crt_basis(n, depth, bits)
@@ -85,10 +87,19 @@ def test_ntt_small_rings(gpu, oracle, hip_env, logn, bits):
     assert np.array_equal(m.to_rns(), ev)
     m.intt_all_in_place()
     assert np.array_equal(m.to_rns(), x)
+    hip_env.set("MXX_HIP_NTT64", "int")
+    i64 = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
+    i64.ntt_all_in_place()
+    assert np.array_equal(i64.to_rns(), ev)
+    i64.intt_all_in_place()
+    assert np.array_equal(i64.to_rns(), x)
+    hip_env.unset("MXX_HIP_NTT64")
     hip_env.set("MXX_HIP_NTT_PATH", "generic")
     g = gpu.GpuDCRTPolyMatrix.from_rns(p, x, False)
     g.ntt_all_in_place()
     assert np.array_equal(g.to_rns(), ev)
+    g.intt_all_in_place()
+    assert np.array_equal(g.to_rns(), x)
 
 
 @pytest.mark.parametrize("logn,bits", [(ln, b) for ln in (10, 11, 12, 13, 14) for b in (51, 50, 49, 45, 33)] +
