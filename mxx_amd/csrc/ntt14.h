@@ -52,8 +52,8 @@ __device__ __forceinline__ void wave_sync() {
 // ADD: the vector `addv` (canonical residues, evaluation order) is added to the result on its way out
 // GPUPOLY_PHASE_TIMING builds only (tools/build_variant.sh phase PHASE_TIMING=1; tools/ab_ntt_phases.sh; the mask comes from
 // MXX_HIP_NTT_PHASE): `phase` switches parts of the kernel off at run time - bit 0: no global loads (synthetic inputs),
-// bit 1: no butterflies, bit 2: no global stores, bit 5: no LDS traffic and no barriers - to time the memory skeleton, the
-// arithmetic and the exchanges separately.  Results are wrong by design in those modes.
+// bit 1: no butterflies, bit 2: no global stores, bit 5: no LDS traffic and no barriers, bit 6: twiddles from registers
+// instead of the tables - to time the memory skeleton, the arithmetic and the exchanges separately.  Results are wrong by design in those modes.
 #ifdef GPUPOLY_PHASE_TIMING
 #define NTT14_PHASE(bit) ((phase & (bit)) != 0)
 #else
@@ -64,7 +64,7 @@ __device__ __forceinline__ void wave_sync() {
 // stores sit 32 bytes apart: each instruction half-fills 64 lines, and the two halves of a line reach the memory side as
 // separate partial writes when the store is non-temporal (streams of 1 GiB and more, the digit transforms of a
 // decomposition): "stores only" ran at 1.7 TB/s there (tools/ab_ntt_phases.sh).
-template <typename W, bool TIGHT, bool NTS, typename Load, bool ADD = false, bool COAL = false>
+template <typename W, bool TIGHT, bool NTS, typename Load, bool ADD = false, bool COAL = false, bool NOTW = false>
 __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> *__restrict__ tw_all,
                                          const LimbConst &lc, uint32_t limb, const W *__restrict__ addv = nullptr,
                                          uint32_t phase = 0) {
@@ -82,7 +82,7 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
     W h[R0];
 #pragma unroll
     for (int u = 0; u < R0; ++u) h[u] = NTT14_PHASE(1) ? static_cast<W>((tid * 2654435761u + u * 40503u + limb) & 0xffffu) : load(tid + T * u);
-    if (!NTT14_PHASE(2)) ct_network_lazy<W, 5>(h, tw, 0, 0, q, twoq);
+    if (!NTT14_PHASE(2)) ct_network_lazy<W, 5, NOTW>(h, tw, 0, 0, q, twoq);
 
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             for (int m = 0; m < 8; ++m) v[m] = NTT14_PHASE(32) ? h[8 * grp + m] : xb[base + 72 * m];  // bit 5: no LDS traffic, no barriers (arithmetic only)
             if (!NTT14_PHASE(2)) {
                 ct_prefold<W, 3, TIGHT>(v, q);
-                ct_network_lazy<W, 3>(v, tw, B, 5, q, twoq);
+                ct_network_lazy<W, 3, NOTW>(v, tw, B, 5, q, twoq);
             }
             if (!NTT14_PHASE(32)) {
 #pragma unroll
@@ -119,7 +119,7 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             }
             if (!NTT14_PHASE(2)) {
                 ct_prefold<W, 3, TIGHT>(v, q);
-                ct_network_lazy<W, 3>(v, tw, B * 8u + c, 8, q, twoq);
+                ct_network_lazy<W, 3, NOTW>(v, tw, B * 8u + c, 8, q, twoq);
             }
             if (!NTT14_PHASE(32)) {
 #pragma unroll
@@ -135,7 +135,7 @@ __device__ __forceinline__ void fwd_body(W *g, const Load load, const TwPair<W> 
             }
             if (!NTT14_PHASE(2)) {
                 ct_prefold<W, 3, TIGHT>(v, q);
-                ct_network_lazy<W, 3>(v, tw, B * 64u + lane, 11, q, twoq);
+                ct_network_lazy<W, 3, NOTW>(v, tw, B * 64u + lane, 11, q, twoq);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = csub<W>(fold_2q<W>(v[m], q, muw), q);
             }
@@ -210,7 +210,9 @@ __global__ void __launch_bounds__(512, 8 / (sizeof(W) / 4))
     W *g = data + vec * N;
 #ifdef GPUPOLY_PHASE_TIMING
     // bit 3 of the phase mask selects the coalesced-store form, bit 4 cacheable stores, whatever the launcher chose
-    if (phase & 8) {
+    if (phase & 64) {  // bit 6: twiddles from registers (no table loads)
+        fwd_body<W, TIGHT, NT, LoadVector<W, NT>, false, NT, true>(g, LoadVector<W, NT>{g}, tw_all, lc, limb, nullptr, phase);
+    } else if (phase & 8) {
         if (phase & 16) fwd_body<W, TIGHT, false, LoadVector<W, NT>, false, true>(g, LoadVector<W, NT>{g}, tw_all, lc, limb, nullptr, phase);
         else fwd_body<W, TIGHT, NT, LoadVector<W, NT>, false, true>(g, LoadVector<W, NT>{g}, tw_all, lc, limb, nullptr, phase);
     } else if (phase & 16) {

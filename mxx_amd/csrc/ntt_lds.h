@@ -106,7 +106,8 @@ __device__ __forceinline__ uint32_t mont_mul_lazy(uint32_t a, uint32_t b, uint32
 }
 
 // ---- forward pass: stages [S_P, S_P + C), Cooley-Tukey, values grow by 2q per stage --------
-template <typename W, int C>
+// NOTW (phase-timing builds only, ntt14.h): every twiddle is a register constant - the arithmetic without its table loads
+template <typename W, int C, bool NOTW = false>
 __device__ __forceinline__ void ct_network_lazy(W (&v)[1 << C], const TwPair<W> *__restrict__ tw, uint32_t bi, int s_p,
                                                 W q, W twoq) {
 #pragma unroll
@@ -116,7 +117,7 @@ __device__ __forceinline__ void ct_network_lazy(W (&v)[1 << C], const TwPair<W> 
 #pragma unroll
         for (int u = 0; u < (1 << C); ++u) {
             if (u & half) continue;
-            const TwPair<W> t = tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
+            const TwPair<W> t = NOTW ? TwPair<W>{static_cast<W>(q - 5u - tb), static_cast<W>(77u + tb)} : tw[tb + (static_cast<uint32_t>(u) >> (C - k))];
             const W V = v[u + half];
             const W nT = V * t.w + mulhi_w(V, t.ws) * q;  // t.w holds -w
             const W U = v[u];

@@ -290,7 +290,7 @@ void EnvSwitches::load() {
     }
     if (const char *e = std::getenv("MXX_HIP_NTT_PHASE")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 63) ntt_phase = v;
+        if (v >= 0 && v <= 127) ntt_phase = v;
     }
     if (const char *e = std::getenv("MXX_HIP_SAMPLER_FILL_EVERY")) {
         const int v = std::atoi(e);

@@ -13,7 +13,7 @@ import mxx_amd as mx
 from mxx_amd import _ffi
 lib = _ffi.lib()
 N = 16384
-names = {37: "butterflies only: no loads, stores, LDS traffic or barriers", 32: "no LDS traffic / barriers", 8: "whole, coalesced stores", 16: "whole, cacheable stores", 24: "whole, coalesced + cacheable", 11: "stores only, coalesced", 19: "stores only, cacheable", 27: "stores only, coalesced + cacheable", 0: "whole kernel", 1: "no loads", 2: "no butterflies", 4: "no stores", 3: "stores only (+LDS)", 5: "butterflies only (+LDS)", 6: "loads only (+LDS)", 7: "LDS traffic + barriers only"}
+names = {101: "butterflies only, twiddles from registers (no memory operation at all)", 64: "whole kernel, twiddles from registers", 37: "butterflies only: no loads, stores, LDS traffic or barriers", 32: "no LDS traffic / barriers", 8: "whole, coalesced stores", 16: "whole, cacheable stores", 24: "whole, coalesced + cacheable", 11: "stores only, coalesced", 19: "stores only, cacheable", 27: "stores only, coalesced + cacheable", 0: "whole kernel", 1: "no loads", 2: "no butterflies", 4: "no stores", 3: "stores only (+LDS)", 5: "butterflies only (+LDS)", 6: "loads only (+LDS)", 7: "LDS traffic + barriers only"}
 for polys in (1024, 4096):
     p = mx.GpuDCRTPolyParams(N, mx.gen_crt_basis(N, 4, 24), 12)
     ctx = p.ctx()
