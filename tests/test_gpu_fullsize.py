@@ -95,11 +95,17 @@ def test_m2b_entries_and_decompose_rows_against_the_oracle(gpu, oracle):
 def test_m3_preimage_relation_and_norm(gpu, oracle, depth):
     p = make_params(gpu, oracle, N, depth, 24, 12)
     sigma, base = 4.578, 12
+    from mxx_amd.sampler import seed_source
+
     sampler = gpu.GpuDCRTPolyTrapdoorSampler(p, sigma)
-    td, A = sampler.trapdoor(p, 1)
     k = p.modulus_digits()
-    target = gpu.GpuDCRTPolyUniformSampler().sample_uniform(p, 1, 50, gpu.DistType.FinRingDist())
-    x = sampler.preimage(p, td, A, target)
+    # fixed seeds (R, E, A_bar | target | p2, p1, z): the bound below is a 6.5-sigma event over 18 million entries - about one
+    # run in a thousand with OS seeds (it happened once in round 5) - so the draw is pinned; the statistics of the samplers
+    # are tested at scale in test_gpu_sampler_stats.py
+    with seed_source(bytes((13 * j + 3 * i + depth) & 0xFF for i in range(32)) for j in range(7)):
+        td, A = sampler.trapdoor(p, 1)
+        target = gpu.GpuDCRTPolyUniformSampler().sample_uniform(p, 1, 50, gpu.DistType.FinRingDist())
+        x = sampler.preimage(p, td, A, target)
     assert x.size() == (k + 2, 50)
     assert A * x == target
     # x is one integer vector, |x| < 6.5 s ~ 2^30 > q_i/2: rebuild it from limbs 0 and 1 (Garner), centre it
